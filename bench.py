@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-pairs/s of PWC-Net inference at 1024x448 fp32 on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A step = one PWCDCNet.forward over this rank's batch of B synthetic image pairs already resident in
+HBM (full HIP path: correlation, warp, MFMA implicit-GEMM convs; HIP-graph replay), plus -- for N>1 --
+the gather of the flow fields to rank 0.  N>1 is launched by torch.distributed.run, one process per
+GPU over RCCL; work per GPU is fixed (weak scaling), no collective inside a forward.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline      -- dominant kernel (the 3x3 MFMA conv, on its heaviest launch dc_conv1) vs fp32-MFMA peak
+  roofline_corr -- the level-2 correlation kernel vs HBM peak (north_star's 60 % target)
+  cpu_baseline  -- the CPU oracle timed on this host's cores on the same 1024x448 workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_CEILING_GBS = 6290.0
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+GAIN, BIAS_STD = 0.85, 0.02    # synthetic-weight recipe shared with tests/golden (mean |flow2| ~ 1)
+
+
+def conv_macs_per_pair(H, W):
+    """MACs of the 81 conv/deconv calls of one forward (reference models/PWCNet.py:184-268)."""
+    from opticalflow_amd.engine import CONTEXT, DENSE_OUT, PYRAMID_CH, level_in_channels
+    total = 0
+    for l in range(1, 7):
+        h, w = H >> l, W >> l
+        cin, c = PYRAMID_CH[l - 1], PYRAMID_CH[l]
+        total += 2 * (c * cin * 9 + 2 * c * c * 9) * h * w            # both images
+    for l in (6, 5, 4, 3, 2):
+        h, w = H >> l, W >> l
+        cin = level_in_channels(l)
+        for co in DENSE_OUT:
+            total += co * cin * 9 * h * w
+            cin += co
+        total += 2 * cin * 9 * h * w                                   # predict_flow
+        if l > 2:
+            total += (2 * 2 + cin * 2) * 16 * h * w                     # deconv + upfeat (4x4 taps per input px)
+    h, w = H >> 2, W >> 2
+    cin = level_in_channels(2) + sum(DENSE_OUT)
+    for co, _ in CONTEXT:
+        total += co * cin * 9 * h * w
+        cin = co
+    total += 2 * cin * 9 * h * w
+    return total
+
+
+def event_time_ms(fn, reps, stream):
+    """Average duration of fn() over `reps` back-to-back launches, HIP events on the launch stream."""
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    fn()
+    stream.synchronize()
+    start.record(stream)
+    for _ in range(reps):
+        fn()
+    stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=448)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--conv-backend", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch.distributed as dist
+    from opticalflow_amd import PWCDCNet, _lib
+    from opticalflow_amd.parallel import broadcast_parameters, gather_flows
+    from opticalflow_amd.weights import synthetic_state_dict
+
+    _lib.load()                                   # no HIP library -> no benchmark
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no ROCm device is visible")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, H, W = args.batch, args.height, args.width
+    net = PWCDCNet(conv_backend=args.conv_backend, use_graph=not args.no_graph)
+    if rank == 0:
+        net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=GAIN, bias_std=BIAS_STD))
+    net = net.to(dev).eval()
+    bcast_bytes = broadcast_parameters(net, src=0) if world > 1 else 0
+
+    x = torch.rand(B, 6, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    counts = [B] * world
+
+    def step():
+        flow = net(x)
+        if world > 1:
+            return gather_flows(flow, counts, dst=0)
+        return flow
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / elapsed
+        macs = conv_macs_per_pair(H, W)
+        result = {
+            "metric": "image-pairs/sec at 1024x448 fp32", "value": round(value, 3), "unit": "image-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform[0,1) image pairs; seeded Kaiming-fan-in weights x0.85, no checkpoint available)",
+            "config": {"workload": "BASELINE configs[2]: batch=%d/GPU %dx%d fp32, full HIP path (corr+warp+MFMA convs)%s"
+                                   % (B, W, H, "" if args.conv_backend == "hip" else " [convs on PyTorch-ROCm: configs[1]]"),
+                       "pairs_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
+                       "conv_backend": args.conv_backend, "hip_graph": not args.no_graph,
+                       "parallelism": "batch-shard x%d, weights broadcast %d B, flow gather to rank 0" % (world, bcast_bytes)},
+            "conv_gflop_per_pair": round(2 * macs / 1e9, 3),
+            "mfma_util_whole_forward": round(2 * macs * value / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+        }
+
+    # ---- per-kernel roofline probes (rank 0; HIP events on the launch stream) -----------------------
+    if rank == 0:
+        plan = net._plan_for(x)
+        stream = torch.cuda.current_stream(dev)
+        h2, w2 = H >> 2, W >> 2
+        if args.conv_backend == "hip":
+            cin = plan.arena[2].shape[1]
+            flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
+            ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
+            ach = flops / (ms * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "conv3x3_mfma_kernel<f32,MT=4,S=1,D=1> (dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
+                                  "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                  "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
+        from opticalflow_amd import ops
+        c2 = 32
+        off = 448 + 81
+        ar = plan.arena[2]
+        bytes_corr = (2 * c2 + 81) * h2 * w2 * 4 * B
+        ms = event_time_ms(lambda: ops.correlation(ar[:, off:off + c2], plan.warped[2], 4, 1, 4, 1, 1, 1.0,
+                                                   leaky_slope=0.1, out=ar[:, 448:529]), 20, stream)
+        gbs = bytes_corr / (ms * 1e-3) / 1e9
+        result["roofline_corr"] = {"kernel": "corr81_kernel<f32> (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena write)" % (w2, h2, B),
+                                   "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
+                                   "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
+        if args.conv_backend != "hip":
+            result["roofline"] = result["roofline_corr"]
+        bytes_warp = (2 * c2 + 2) * h2 * w2 * 4 * B
+        ms = event_time_ms(lambda: ops.warp(plan.c2[2], ar[:, off + c2:off + c2 + 2], 5.0, False, out=plan.warped[2]), 20, stream)
+        result["roofline_warp"] = {"kernel": "warp_kernel<f32> (level 2)", "bound": "hbm",
+                                   "achieved": round(bytes_warp / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4)}
+
+        # ---- parity spot check + CPU baseline (the oracle is the checker / the baseline, never the product)
+        from oracle import pwc_oracle as O
+        sd_cpu = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        xs = torch.rand(1, 6, 64, 128, generator=torch.Generator().manual_seed(7))
+        with torch.no_grad():
+            ref = O.pwc_forward(sd_cpu, xs)
+        result["epe_vs_cpu_oracle_64x128"] = float("%.3e" % O.epe(net(xs.to(dev)).cpu(), ref))
+        if world == 1 and not args.no_cpu_baseline:
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            torch.set_num_threads(cores)
+            xc = torch.rand(1, 6, H, W, generator=torch.Generator().manual_seed(1234))
+            with torch.no_grad():
+                O.pwc_forward(sd_cpu, xc)
+                n, t0 = 0, time.perf_counter()
+                while True:
+                    O.pwc_forward(sd_cpu, xc)
+                    n += 1
+                    dt = time.perf_counter() - t0
+                    if dt >= args.cpu_seconds or n >= 50:
+                        break
+            result["cpu_baseline"] = {"value": round(n / dt, 3), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+                                      "sample": "%d forwards of 1x6x%dx%d fp32 by oracle/pwc_oracle.py (torch CPU, %d threads) after 1 warm-up"
+                                                % (n, H, W, cores)}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

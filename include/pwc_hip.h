@@ -1,0 +1,110 @@
+/*
+ * pwc_hip.h -- C ABI of libpwc_hip.so, the MI355X (gfx950) replacement for the
+ * native half of the reference's PWC-Net inference path.
+ *
+ * Every entry point
+ *   - takes plain device pointers, sizes and an opaque HIP stream handle
+ *     (void* == hipStream_t; NULL = the null stream),
+ *   - never allocates, frees or synchronises (graph-capturable),
+ *   - returns 0 on success, a negative PWC_E* code for an argument the kernel
+ *     cannot honour (nothing launched), or a positive hipError_t when the
+ *     launch failed.  pwc_last_error() returns a thread-local message.
+ *
+ * Reference interfaces replaced (paths relative to the reference root):
+ *   pwc_corr_fwd        correlation_cuda.forward  models/correlation_package/correlation_cuda.cc:10-87
+ *                       (+ channels_first / correlation_forward kernels,
+ *                        correlation_cuda_kernel.cu:46-147, launcher :336-427)
+ *                       and the fallback semantics of correlation.py:12-40
+ *   pwc_corr_bwd        correlation_cuda.backward correlation_cuda.cc:89-167, kernels .cu:150-334
+ *   pwc_warp_fwd        PWCDCNet.warp             models/PWCNet.py:141-177
+ *   pwc_conv2d_fwd      conv()/predict_flow()     models/PWCNet.py:26-33 (nn.Conv2d 3x3 + LeakyReLU(0.1))
+ *   pwc_deconv4x4s2_fwd deconv()                  models/PWCNet.py:35-36 (nn.ConvTranspose2d k4 s2 p1)
+ *
+ * All tensors are NCHW with contiguous C,H,W planes; only the batch stride is
+ * free (in ELEMENTS), so an operand may be a channel slice of a wider
+ * [B, Ctot, H, W] arena (this is how the DenseNet concatenations of
+ * PWCNet.py:202-264 are done without copies).
+ */
+#ifndef PWC_HIP_H_
+#define PWC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWC_ABI_VERSION 1
+
+/* element types */
+#define PWC_F32 0
+#define PWC_F16 1
+
+/* error codes (negative = argument error, positive = hipError_t) */
+#define PWC_OK 0
+#define PWC_EINVAL (-1)     /* bad shape / size / null pointer            */
+#define PWC_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
+#define PWC_EALIGN (-3)     /* pointer or stride alignment not met        */
+
+/* pwc_corr_fwd / pwc_conv2d_fwd flags */
+#define PWC_CORR_NORMALIZE 1u /* divide by kernel_size^2*C (correlation_cuda_kernel.cu:104,143) instead of
+                                 multiplying by corr_multiply (correlation.py:35-36)              */
+#define PWC_ACT_LEAKY 2u      /* fuse LeakyReLU(slope) into the epilogue (PWCNet.py:72,199)          */
+#define PWC_CONV_RESIDUAL 4u  /* y += residual (flow2 + dc_conv7(...), PWCNet.py:268)                */
+
+int pwc_abi_version(void);
+const char *pwc_last_error(void);
+
+/* Cost volume.  in1,in2: [B,C,H,W]; out: [B,(2*(max_disp/stride2)+1)^2,outH,outW] with
+ * outH = ceil((H + 2*pad - 2*((k-1)/2 + max_disp)) / stride1)   (correlation_cuda.cc:25-38).
+ * out[b,(tj+r)*D+(ti+r),y,x] = sum_{k x k} sum_c in1p[..]*in2p[..], displacement order tj(dy) outer,
+ * ti(dx) inner (correlation_cuda_kernel.cu:107-141; identical to correlation.py:28-29). */
+int pwc_corr_fwd(const void *in1, const void *in2, void *out,
+                 int B, int C, int H, int W,
+                 int pad_size, int kernel_size, int max_disp, int stride1, int stride2,
+                 float corr_multiply, int dtype, unsigned flags, float leaky_slope,
+                 int64_t in1_bstride, int64_t in2_bstride, int64_t out_bstride,
+                 void *stream);
+
+/* Gradients of pwc_corr_fwd w.r.t. in1 and in2 (no fused activation; same scale rule as forward). */
+int pwc_corr_bwd(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,
+                 int B, int C, int H, int W,
+                 int pad_size, int kernel_size, int max_disp, int stride1, int stride2,
+                 float corr_multiply, int dtype, unsigned flags,
+                 void *stream);
+
+/* Backward warp of x by (flow_scale * flo): bilinear, zero padding, times the validity mask
+ * [sum of in-bounds bilinear weights >= mask_threshold]  (PWCNet.py:141-177).
+ * x,out: [B,C,H,W]; flo: [B,2,H,W] (u then v).  align_corners=0 reproduces the reference as executed
+ * by torch>=1.3: x_src = (x+u)*W/(W-1) - 0.5. */
+int pwc_warp_fwd(const void *x, const void *flo, void *out,
+                 int B, int C, int H, int W,
+                 float flow_scale, int align_corners, float mask_threshold, int dtype,
+                 int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride,
+                 void *stream);
+
+/* Bytes needed for the packed (kernel-native) form of a [Cout,Cin,3,3] filter bank. */
+int64_t pwc_conv3x3_packed_bytes(int Cin, int Cout, int dtype);
+/* Repack w:[Cout,Cin,3,3] (device, NCHW filter layout of nn.Conv2d) into wp (device). */
+int pwc_conv3x3_pack(const void *w, void *wp, int Cin, int Cout, int dtype, void *stream);
+
+/* 3x3 convolution, padding == dilation (so H,W are preserved at stride 1; Hout = (H-1)/stride+1),
+ * + bias, optional LeakyReLU and residual.  x:[B,Cin,H,W], y:[B,Cout,Hout,Wout],
+ * wp = output of pwc_conv3x3_pack, bias:[Cout] f32, residual: same geometry as y or NULL. */
+int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, const void *residual, void *y,
+                   int B, int Cin, int H, int W, int Cout,
+                   int stride, int dilation, int dtype, unsigned flags, float leaky_slope,
+                   int64_t x_bstride, int64_t y_bstride, int64_t res_bstride,
+                   void *stream);
+
+/* ConvTranspose2d(kernel 4, stride 2, padding 1) + bias.  x:[B,Cin,H,W], w:[Cin,Cout,4,4] (nn layout),
+ * y:[B,Cout,2H,2W]. */
+int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bias, void *y,
+                        int B, int Cin, int H, int W, int Cout, int dtype,
+                        int64_t x_bstride, int64_t y_bstride,
+                        void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWC_HIP_H_ */

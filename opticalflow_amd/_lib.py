@@ -1,0 +1,77 @@
+"""ctypes binding of libpwc_hip.so (the C ABI declared in include/pwc_hip.h).
+
+The library is the product: if it is missing or fails to load, every operator
+raises -- there is no CPU or eager-PyTorch fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpwc_hip.so")
+
+ABI_VERSION = 1
+PWC_F32, PWC_F16 = 0, 1
+FLAG_CORR_NORMALIZE = 1
+FLAG_ACT_LEAKY = 2
+FLAG_CONV_RESIDUAL = 4
+
+# name -> (restype, argtypes); mirrors include/pwc_hip.h one to one
+SIGNATURES = {
+    "pwc_abi_version": (c_int, []),
+    "pwc_last_error": (c_char_p, []),
+    "pwc_corr_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_float,
+                             c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_corr_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                             c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_void_p]),
+    "pwc_warp_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                             c_float, c_int, c_float, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_conv3x3_packed_bytes": (c_int64, [c_int, c_int, c_int]),
+    "pwc_conv3x3_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "pwc_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
+                               c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_deconv4x4s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class PwcHipError(RuntimeError):
+    """Raised when libpwc_hip.so is unavailable or a call returns non-zero."""
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PwcHipError(
+            "libpwc_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C opticalflow_amd/csrc`; the HIP path has no fallback" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise PwcHipError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PwcHipError("libpwc_hip.so does not export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.pwc_abi_version()
+    if got != ABI_VERSION:
+        raise PwcHipError("libpwc_hip.so ABI %d, binding expects %d -- rebuild" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().pwc_last_error()
+        raise PwcHipError("%s failed (code %d): %s" % (what, rc, msg.decode("utf-8", "replace") if msg else "?"))

@@ -1,0 +1,372 @@
+// Cost-volume correlation for gfx950 (MI355X).
+//
+// Replaces the reference's channels_first + correlation_forward CUDA kernels
+// (models/correlation_package/correlation_cuda_kernel.cu:46-147) and their launcher
+// (:336-427).  Semantics kept: output channel order tc = (dy+r)*D + (dx+r), zero padding,
+// fp32 accumulation; NOT kept: the NHWC scratch round trip, the one-pixel-per-32-thread-block
+// layout and the 81 serial shuffle reductions.
+//
+// Fast path (kernel_size 1, max_disp 4, stride1 = stride2 = 1, pad 4 -- the only
+// configuration PWCDCNet instantiates, PWCNet.py:71):
+//   * one workgroup = 9 wavefronts = one 8 x 32 pixel tile; wave w owns displacement row
+//     dy = w - 4, so dy is wave-uniform and the 81-neighbour product needs no cross-lane
+//     reduction: every lane owns 4 consecutive pixels x 9 dx = 36 fp32 accumulators;
+//   * both feature maps are read NCHW with 16-byte coalesced loads along W (rows are
+//     contiguous in W -- no transpose needed) and staged per 8-channel chunk in LDS: the in1
+//     tile (8 x 32) and the in2 displacement tile with its +-4 halo (16 x 40);
+//   * per channel a lane issues 4 ds_read_b128 (1 for in1, 3 for the 12-wide in2 window) and
+//     36 v_fma; the lane -> (row, column-group) map is chosen so that each ds_read_b128 lane
+//     group covers rows {k, k+4}, which with a 40-float row pitch touches all 64 banks once;
+//   * epilogue fuses the scale (corr_multiply or 1/C) and LeakyReLU and stores 128-byte row
+//     segments straight into the caller's [B,81,H,W] slot (batch stride free, so the slot can
+//     live inside the decoder's concat arena).
+// Generic path (any pad/kernel/stride): one thread per output element, used only by callers
+// other than PWCDCNet.
+#include "pwc_common.h"
+
+namespace {
+
+using pwc::from_f32;
+using pwc::leaky;
+using pwc::to_f32;
+
+constexpr int kD = 4;               // max displacement of the fast path
+constexpr int kND = 2 * kD + 1;     // 9
+constexpr int kPX = 4;              // pixels per lane
+constexpr int kTH = 8;              // tile rows
+constexpr int kTG = 8;              // 4-pixel groups per tile row
+constexpr int kTW = kTG * kPX;      // 32 tile columns
+constexpr int kPitch = 40;          // floats per LDS row (10 x 16 B): 4 rows apart == 8 slots mod 16
+constexpr int kS2Rows = kTH + 2 * kD;            // 16
+constexpr int kS2Quads = (kTW + 2 * kD) / 4;     // 10 float4 per in2 row
+constexpr int kThreads = 64 * kND;  // 576
+
+template <int CK>
+struct CorrSmem {
+    float s1[CK][kTH][kPitch];
+    float s2[CK][kS2Rows][kPitch];
+};
+
+// ds_read_b128 services a wave in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and the
+// same +32 (MI355X microarch guide, LDS table).  Give group k the tile rows {k, k+4}.
+__device__ __forceinline__ void lane_to_rg(int lane, int &r, int &g) {
+    const int l = lane & 31;
+    int grp, pos;
+    if (l < 4)       { grp = 0; pos = l; }
+    else if (l < 12) { grp = 1; pos = l - 4; }
+    else if (l < 16) { grp = 0; pos = l - 8; }
+    else if (l < 20) { grp = 1; pos = l - 8; }
+    else if (l < 28) { grp = 0; pos = l - 12; }
+    else             { grp = 1; pos = l - 16; }
+    grp += (lane >> 5) * 2;
+    r = grp + 4 * (pos >> 3);
+    g = pos & 7;
+}
+
+template <typename T>
+__device__ __forceinline__ float4 load_quad(const T *__restrict__ row, int x, int W, bool row_ok, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!row_ok) return v;
+    if (vec) {
+        if (x >= 0 && x < W) {
+            if constexpr (sizeof(T) == 4) {
+                v = *reinterpret_cast<const float4 *>(row + x);
+            } else {
+                const uint2 raw = *reinterpret_cast<const uint2 *>(row + x);
+                const __half2 lo = *reinterpret_cast<const __half2 *>(&raw.x);
+                const __half2 hi = *reinterpret_cast<const __half2 *>(&raw.y);
+                v = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+            }
+        }
+    } else {
+        if (x >= 0 && x < W) v.x = to_f32<T>(row[x]);
+        if (x + 1 >= 0 && x + 1 < W) v.y = to_f32<T>(row[x + 1]);
+        if (x + 2 >= 0 && x + 2 < W) v.z = to_f32<T>(row[x + 2]);
+        if (x + 3 >= 0 && x + 3 < W) v.w = to_f32<T>(row[x + 3]);
+    }
+    return v;
+}
+
+template <typename T, int CK>
+__global__ void __launch_bounds__(kThreads)
+corr81_kernel(const T *__restrict__ in1, const T *__restrict__ in2, T *__restrict__ out,
+              int C, int H, int W, int tiles_x, int tiles_y,
+              int64_t bs1, int64_t bs2, int64_t bso,
+              float scale, float slope, int do_leaky, int vec) {
+    __shared__ __attribute__((aligned(16))) CorrSmem<CK> sm;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;            // displacement row index dyi = dy + 4 (wave-uniform)
+    const int lane = tid & 63;
+    int r, g;
+    lane_to_rg(lane, r, g);
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * kTW;
+    const int y0 = ty * kTH;
+
+    const int64_t plane = (int64_t)H * W;
+    const T *p1 = in1 + (int64_t)b * bs1;
+    const T *p2 = in2 + (int64_t)b * bs2;
+
+    float acc[kND][kPX];
+#pragma unroll
+    for (int dx = 0; dx < kND; ++dx)
+#pragma unroll
+        for (int p = 0; p < kPX; ++p) acc[dx][p] = 0.f;
+
+    constexpr int kQ1 = CK * kTH * kTG;             // float4 slots of the in1 chunk
+    constexpr int kQ2 = CK * kS2Rows * kS2Quads;    // float4 slots of the in2 chunk
+
+    for (int c0 = 0; c0 < C; c0 += CK) {
+        if (c0) __syncthreads();                    // previous chunk fully consumed
+        for (int i = tid; i < kQ1 + kQ2; i += kThreads) {
+            if (i < kQ1) {
+                const int c = i / (kTH * kTG);
+                const int row = (i / kTG) % kTH;
+                const int q = i % kTG;
+                const int y = y0 + row;
+                const bool ok = (c0 + c < C) && (y < H);
+                const float4 v = load_quad<T>(p1 + (int64_t)(c0 + c) * plane + (int64_t)y * W, x0 + 4 * q, W, ok, vec);
+                *reinterpret_cast<float4 *>(&sm.s1[c][row][4 * q]) = v;
+            } else {
+                const int j = i - kQ1;
+                const int c = j / (kS2Rows * kS2Quads);
+                const int rem = j % (kS2Rows * kS2Quads);
+                const int row = rem / kS2Quads;
+                const int q = rem % kS2Quads;
+                const int y = y0 + row - kD;
+                const bool ok = (c0 + c < C) && (y >= 0) && (y < H);
+                const float4 v = load_quad<T>(p2 + (int64_t)(c0 + c) * plane + (int64_t)y * W, x0 + 4 * q - kD, W, ok, vec);
+                *reinterpret_cast<float4 *>(&sm.s2[c][row][4 * q]) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(&sm.s1[c][r][4 * g]);
+            const float4 w0 = *reinterpret_cast<const float4 *>(&sm.s2[c][r + wave][4 * g]);
+            const float4 w1 = *reinterpret_cast<const float4 *>(&sm.s2[c][r + wave][4 * g + 4]);
+            const float4 w2 = *reinterpret_cast<const float4 *>(&sm.s2[c][r + wave][4 * g + 8]);
+            const float a[kPX] = {a4.x, a4.y, a4.z, a4.w};
+            const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+            for (int dx = 0; dx < kND; ++dx)
+#pragma unroll
+                for (int p = 0; p < kPX; ++p) acc[dx][p] = fmaf(a[p], w[p + dx], acc[dx][p]);
+        }
+    }
+
+    const int y = y0 + r;
+    const int x = x0 + 4 * g;
+    if (y >= H || x >= W) return;
+    T *po = out + (int64_t)b * bso + (int64_t)(wave * kND) * plane + (int64_t)y * W + x;
+#pragma unroll
+    for (int dx = 0; dx < kND; ++dx) {
+        float v[kPX];
+#pragma unroll
+        for (int p = 0; p < kPX; ++p) {
+            v[p] = acc[dx][p] * scale;
+            if (do_leaky) v[p] = leaky(v[p], slope);
+        }
+        T *q = po + (int64_t)dx * plane;
+        if (vec) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                __half2 lo = __floats2half2_rn(v[0], v[1]);
+                __half2 hi = __floats2half2_rn(v[2], v[3]);
+                uint2 raw;
+                raw.x = *reinterpret_cast<unsigned *>(&lo);
+                raw.y = *reinterpret_cast<unsigned *>(&hi);
+                *reinterpret_cast<uint2 *>(q) = raw;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < kPX; ++p)
+                if (x + p < W) q[p] = from_f32<T>(v[p]);
+        }
+    }
+}
+
+// Any (pad, kernel, max_disp, stride1, stride2): one thread per output element.
+template <typename T>
+__global__ void __launch_bounds__(256)
+corr_generic_kernel(const T *__restrict__ in1, const T *__restrict__ in2, T *__restrict__ out,
+                    int C, int H, int W, int nch, int oh, int ow,
+                    int pad, int krad, int max_disp, int s1, int s2, int drad,
+                    int64_t bs1, int64_t bs2, int64_t bso, int64_t total,
+                    float scale, float slope, int do_leaky) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % ow);
+    int64_t t = idx / ow;
+    const int oy = (int)(t % oh);
+    t /= oh;
+    const int tc = (int)(t % nch);
+    const int b = (int)(t / nch);
+    const int Dd = 2 * drad + 1;
+    const int tj = tc / Dd - drad;
+    const int ti = tc % Dd - drad;
+    // coordinates in the padded frame, then back to the unpadded one
+    const int y1 = oy * s1 + max_disp - pad;
+    const int x1 = ox * s1 + max_disp - pad;
+    const int y2 = y1 + tj * s2;
+    const int x2 = x1 + ti * s2;
+    const int64_t plane = (int64_t)H * W;
+    const T *p1 = in1 + (int64_t)b * bs1;
+    const T *p2 = in2 + (int64_t)b * bs2;
+    float acc = 0.f;
+    for (int j = -krad; j <= krad; ++j) {
+        for (int i = -krad; i <= krad; ++i) {
+            const int ya = y1 + j, xa = x1 + i, yb = y2 + j, xb = x2 + i;
+            if (ya < 0 || ya >= H || xa < 0 || xa >= W || yb < 0 || yb >= H || xb < 0 || xb >= W) continue;
+            const T *qa = p1 + (int64_t)ya * W + xa;
+            const T *qb = p2 + (int64_t)yb * W + xb;
+            for (int c = 0; c < C; ++c) acc = fmaf(to_f32<T>(qa[c * plane]), to_f32<T>(qb[c * plane]), acc);
+        }
+    }
+    float v = acc * scale;
+    if (do_leaky) v = leaky(v, slope);
+    out[(int64_t)b * bso + (int64_t)tc * oh * ow + (int64_t)oy * ow + ox] = from_f32<T>(v);
+}
+
+// ---- backward (kernel_size 1, stride1 1): gather form, one thread per input element ----------
+template <typename T>
+__global__ void __launch_bounds__(256)
+corr_bwd_kernel(const T *__restrict__ in1, const T *__restrict__ in2, const T *__restrict__ gout,
+                T *__restrict__ g1, T *__restrict__ g2,
+                int C, int H, int W, int drad, int s2, int64_t total, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % W);
+    int64_t t = idx / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    const int Dd = 2 * drad + 1;
+    const int64_t plane = (int64_t)H * W;
+    const T *go = gout + (int64_t)b * Dd * Dd * plane;
+    const T *a = in1 + ((int64_t)b * C + c) * plane;
+    const T *bb = in2 + ((int64_t)b * C + c) * plane;
+    float s1acc = 0.f, s2acc = 0.f;
+    for (int tj = -drad; tj <= drad; ++tj) {
+        for (int ti = -drad; ti <= drad; ++ti) {
+            const int tc = (tj + drad) * Dd + (ti + drad);
+            const int dy = tj * s2, dx = ti * s2;
+            // d in1[y,x] += gout[tc,y,x] * in2[y+dy,x+dx]
+            const int yb = y + dy, xb = x + dx;
+            if (yb >= 0 && yb < H && xb >= 0 && xb < W)
+                s1acc = fmaf(to_f32<T>(go[tc * plane + (int64_t)y * W + x]), to_f32<T>(bb[(int64_t)yb * W + xb]), s1acc);
+            // d in2[y,x] += gout[tc,y-dy,x-dx] * in1[y-dy,x-dx]
+            const int ya = y - dy, xa = x - dx;
+            if (ya >= 0 && ya < H && xa >= 0 && xa < W)
+                s2acc = fmaf(to_f32<T>(go[tc * plane + (int64_t)ya * W + xa]), to_f32<T>(a[(int64_t)ya * W + xa]), s2acc);
+        }
+    }
+    g1[idx] = from_f32<T>(s1acc * scale);
+    g2[idx] = from_f32<T>(s2acc * scale);
+}
+
+template <typename T>
+int launch_corr(const void *in1, const void *in2, void *out, int B, int C, int H, int W,
+                int pad, int ksz, int max_disp, int s1, int s2, float scale, unsigned flags, float slope,
+                int64_t bs1, int64_t bs2, int64_t bso, hipStream_t st) {
+    const int krad = (ksz - 1) / 2;
+    const int drad = max_disp / s2;
+    const int Dd = 2 * drad + 1;
+    const int nch = Dd * Dd;
+    const int border = krad + max_disp;
+    const int oh = (H + 2 * pad - 2 * border + s1 - 1) / s1;
+    const int ow = (W + 2 * pad - 2 * border + s1 - 1) / s1;
+    if (oh <= 0 || ow <= 0) PWC_FAIL(PWC_EINVAL, "pwc_corr_fwd: empty output (%d x %d)", oh, ow);
+    const int do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
+    const T *a = static_cast<const T *>(in1);
+    const T *b = static_cast<const T *>(in2);
+    T *o = static_cast<T *>(out);
+
+    if (ksz == 1 && max_disp == kD && pad == kD && s1 == 1 && s2 == 1) {
+        const int tiles_x = (W + kTW - 1) / kTW;
+        const int tiles_y = (H + kTH - 1) / kTH;
+        const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+        if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr_fwd: grid too large");
+        const int elt = (int)sizeof(T);
+        const int va = 4;  // elements per vector access
+        const bool ptr_ok = ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2) |
+                              reinterpret_cast<uintptr_t>(out)) & (uintptr_t)(va * elt - 1)) == 0;
+        const int vec = (W % 4 == 0) && ptr_ok && (bs1 % 4 == 0) && (bs2 % 4 == 0) && (bso % 4 == 0);
+        hipLaunchKernelGGL((corr81_kernel<T, 8>), dim3((unsigned)nblk), dim3(kThreads), 0, st,
+                           a, b, o, C, H, W, tiles_x, tiles_y, bs1, bs2, bso, scale, slope, do_leaky, vec);
+        return pwc::check_launch("corr81_kernel");
+    }
+    const int64_t total = (int64_t)B * nch * oh * ow;
+    const int64_t nblk = (total + 255) / 256;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr_fwd: grid too large");
+    hipLaunchKernelGGL((corr_generic_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st,
+                       a, b, o, C, H, W, nch, oh, ow, pad, krad, max_disp, s1, s2, drad,
+                       bs1, bs2, bso, total, scale, slope, do_leaky);
+    return pwc::check_launch("corr_generic_kernel");
+}
+
+}  // namespace
+
+extern "C" int pwc_corr_fwd(const void *in1, const void *in2, void *out,
+                            int B, int C, int H, int W,
+                            int pad_size, int kernel_size, int max_disp, int stride1, int stride2,
+                            float corr_multiply, int dtype, unsigned flags, float leaky_slope,
+                            int64_t in1_bstride, int64_t in2_bstride, int64_t out_bstride,
+                            void *stream) {
+    if (!in1 || !in2 || !out) PWC_FAIL(PWC_EINVAL, "pwc_corr_fwd: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_corr_fwd: bad shape %dx%dx%dx%d", B, C, H, W);
+    if (kernel_size < 1 || (kernel_size & 1) == 0 || max_disp < 0 || stride1 < 1 || stride2 < 1 || pad_size < 0)
+        PWC_FAIL(PWC_EINVAL, "pwc_corr_fwd: bad parameters pad=%d k=%d d=%d s1=%d s2=%d", pad_size, kernel_size,
+                 max_disp, stride1, stride2);
+    const int64_t chw = (int64_t)C * H * W;
+    if (in1_bstride < chw || in2_bstride < chw) PWC_FAIL(PWC_EINVAL, "pwc_corr_fwd: input batch stride < C*H*W");
+    const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)(kernel_size * kernel_size * C) : corr_multiply;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PWC_F32:
+            return launch_corr<float>(in1, in2, out, B, C, H, W, pad_size, kernel_size, max_disp, stride1, stride2,
+                                      scale, flags, leaky_slope, in1_bstride, in2_bstride, out_bstride, st);
+        case PWC_F16:
+            return launch_corr<__half>(in1, in2, out, B, C, H, W, pad_size, kernel_size, max_disp, stride1, stride2,
+                                       scale, flags, leaky_slope, in1_bstride, in2_bstride, out_bstride, st);
+        default:
+            PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr_fwd: dtype %d", dtype);
+    }
+}
+
+extern "C" int pwc_corr_bwd(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,
+                            int B, int C, int H, int W,
+                            int pad_size, int kernel_size, int max_disp, int stride1, int stride2,
+                            float corr_multiply, int dtype, unsigned flags, void *stream) {
+    if (!in1 || !in2 || !grad_out || !grad_in1 || !grad_in2) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: bad shape");
+    if (kernel_size != 1 || stride1 != 1 || pad_size != max_disp || stride2 < 1)
+        PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr_bwd: only kernel_size=1, stride1=1, pad_size=max_disp (got k=%d s1=%d pad=%d d=%d)",
+                 kernel_size, stride1, pad_size, max_disp);
+    const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
+    const int drad = max_disp / stride2;
+    const int64_t total = (int64_t)B * C * H * W;
+    const int64_t nblk = (total + 255) / 256;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: grid too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == PWC_F32) {
+        hipLaunchKernelGGL((corr_bwd_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st,
+                           (const float *)in1, (const float *)in2, (const float *)grad_out, (float *)grad_in1,
+                           (float *)grad_in2, C, H, W, drad, stride2, total, scale);
+    } else if (dtype == PWC_F16) {
+        hipLaunchKernelGGL((corr_bwd_kernel<__half>), dim3((unsigned)nblk), dim3(256), 0, st,
+                           (const __half *)in1, (const __half *)in2, (const __half *)grad_out, (__half *)grad_in1,
+                           (__half *)grad_in2, C, H, W, drad, stride2, total, scale);
+    } else {
+        PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr_bwd: dtype %d", dtype);
+    }
+    return pwc::check_launch("corr_bwd_kernel");
+}

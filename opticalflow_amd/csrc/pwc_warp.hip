@@ -1,0 +1,174 @@
+// Fused bilinear backward-warp + validity mask for gfx950.
+//
+// Replaces PWCDCNet.warp (reference models/PWCNet.py:141-177), which builds the mesh on the host,
+// copies it and a ones tensor to the device and calls grid_sample twice.  Here one kernel computes
+// the source coordinate of a pixel once, derives the four taps, their weights and the mask from
+// them, and reuses all of it across the C channels.
+//
+// Coordinates (fp32 always, also for fp16 tensors):
+//   g  = 2*(x + s*u)/max(W-1,1) - 1                              (PWCNet.py:162)
+//   ix = ((g+1)*W - 1)/2        align_corners = 0  (what torch>=1.3 executes for PWCNet.py:166)
+//   ix = (g+1)/2*(W-1)          align_corners = 1
+// evaluated in exactly this operation order so that pixels whose mask sum sits on the 0.9999
+// threshold (PWCNet.py:174) fall on the same side as in the reference.
+//
+// Work split: one thread = 4 consecutive pixels of one row for a block of CPT channels; lanes of a
+// wave cover 256 consecutive pixels, so the stores are 16 B/lane contiguous and the tap gathers of a
+// smooth flow field stay within a few cache lines per wave.  HBM-bound: algorithmic bytes
+// (2*C + 2)*H*W*sizeof(T) per image.
+#include "pwc_common.h"
+
+namespace {
+
+using pwc::from_f32;
+using pwc::to_f32;
+
+constexpr int kWarpThreads = 256;
+constexpr int kCPT = 8;  // channels per thread-iteration block (gridDim.y splits C)
+
+struct Taps {
+    int o00, o01, o10, o11;     // element offsets inside a plane (clamped, always valid)
+    float w00, w01, w10, w11;   // bilinear weight * in-bounds * mask
+};
+
+__device__ __forceinline__ Taps make_taps(float px, float py, int H, int W, int align_corners, float thr) {
+    const float gx = 2.0f * px / (float)max(W - 1, 1) - 1.0f;
+    const float gy = 2.0f * py / (float)max(H - 1, 1) - 1.0f;
+    float ix, iy;
+    if (align_corners) {
+        ix = (gx + 1.0f) / 2.0f * (float)(W - 1);
+        iy = (gy + 1.0f) / 2.0f * (float)(H - 1);
+    } else {
+        ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+        iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    }
+    // keep the integer conversion defined for wild flows; anything this far out has no valid tap
+    ix = fminf(fmaxf(ix, -16.0f), (float)W + 16.0f);
+    iy = fminf(fmaxf(iy, -16.0f), (float)H + 16.0f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float ax1 = ix - fx, ay1 = iy - fy;
+    const float ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
+    const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x0 + 1 >= 0) && (x0 + 1 < W);
+    const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y0 + 1 >= 0) && (y0 + 1 < H);
+    Taps t;
+    t.w00 = (vx0 && vy0) ? ay0 * ax0 : 0.0f;
+    t.w01 = (vx1 && vy0) ? ay0 * ax1 : 0.0f;
+    t.w10 = (vx0 && vy1) ? ay1 * ax0 : 0.0f;
+    t.w11 = (vx1 && vy1) ? ay1 * ax1 : 0.0f;
+    // grid_sample(ones) accumulates nw, ne, sw, se in this order (same order as the value sum)
+    const float msum = ((t.w00 + t.w01) + t.w10) + t.w11;
+    if (!(msum >= thr)) { t.w00 = t.w01 = t.w10 = t.w11 = 0.0f; }
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    t.o00 = yc0 * W + xc0;
+    t.o01 = yc0 * W + xc1;
+    t.o10 = yc1 * W + xc0;
+    t.o11 = yc1 * W + xc1;
+    return t;
+}
+
+__device__ __forceinline__ float tap4(const Taps &t, float v00, float v01, float v10, float v11) {
+    // same association as grid_sample's CPU kernel: ((nw + ne) + sw) + se
+    return ((v00 * t.w00 + v01 * t.w01) + v10 * t.w10) + v11 * t.w11;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kWarpThreads)
+warp_kernel(const T *__restrict__ x, const T *__restrict__ flo, T *__restrict__ out,
+            int C, int H, int W, int quads_per_row, int64_t nquads,
+            int64_t bsx, int64_t bsf, int64_t bso,
+            float flow_scale, int align_corners, float thr, int vec) {
+    const int64_t qi = (int64_t)blockIdx.x * kWarpThreads + threadIdx.x;
+    if (qi >= nquads) return;
+    const int qx = (int)(qi % quads_per_row);
+    int64_t t = qi / quads_per_row;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const int x0 = qx * 4;
+    const int64_t plane = (int64_t)H * W;
+    const T *fu = flo + (int64_t)b * bsf + (int64_t)y * W + x0;
+    const T *fv = fu + plane;
+    const int npx = min(4, W - x0);
+
+    Taps tp[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int pp = (p < npx) ? p : 0;
+        const float u = to_f32<T>(fu[pp]) * flow_scale;
+        const float v = to_f32<T>(fv[pp]) * flow_scale;
+        tp[p] = make_taps((float)(x0 + pp) + u, (float)y + v, H, W, align_corners, thr);
+    }
+
+    const int c_begin = blockIdx.y * kCPT;
+    const int c_end = min(C, c_begin + kCPT);
+    const T *src = x + (int64_t)b * bsx + (int64_t)c_begin * plane;
+    T *dst = out + (int64_t)b * bso + (int64_t)c_begin * plane + (int64_t)y * W + x0;
+    for (int c = c_begin; c < c_end; ++c, src += plane, dst += plane) {
+        float r[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const Taps &q = tp[p];
+            r[p] = tap4(q, to_f32<T>(src[q.o00]), to_f32<T>(src[q.o01]), to_f32<T>(src[q.o10]), to_f32<T>(src[q.o11]));
+        }
+        if (vec) {
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+            } else {
+                __half2 lo = __floats2half2_rn(r[0], r[1]);
+                __half2 hi = __floats2half2_rn(r[2], r[3]);
+                uint2 raw;
+                raw.x = *reinterpret_cast<unsigned *>(&lo);
+                raw.y = *reinterpret_cast<unsigned *>(&hi);
+                *reinterpret_cast<uint2 *>(dst) = raw;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (p < npx) dst[p] = from_f32<T>(r[p]);
+        }
+    }
+}
+
+template <typename T>
+int launch_warp(const void *x, const void *flo, void *out, int B, int C, int H, int W,
+                float flow_scale, int align_corners, float thr,
+                int64_t bsx, int64_t bsf, int64_t bso, hipStream_t st) {
+    const int quads_per_row = (W + 3) / 4;
+    const int64_t nquads = (int64_t)B * H * quads_per_row;
+    const int64_t nblk = (nquads + kWarpThreads - 1) / kWarpThreads;
+    const int cblk = (C + kCPT - 1) / kCPT;
+    if (nblk > 0x7fffffffLL || cblk > 65535) PWC_FAIL(PWC_EINVAL, "pwc_warp_fwd: grid too large");
+    const uintptr_t amask = (uintptr_t)(4 * sizeof(T) - 1);
+    const int vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & amask) == 0) && (bso % 4 == 0);
+    hipLaunchKernelGGL((warp_kernel<T>), dim3((unsigned)nblk, (unsigned)cblk), dim3(kWarpThreads), 0, st,
+                       static_cast<const T *>(x), static_cast<const T *>(flo), static_cast<T *>(out),
+                       C, H, W, quads_per_row, nquads, bsx, bsf, bso, flow_scale, align_corners, thr, vec);
+    return pwc::check_launch("warp_kernel");
+}
+
+}  // namespace
+
+extern "C" int pwc_warp_fwd(const void *x, const void *flo, void *out,
+                            int B, int C, int H, int W,
+                            float flow_scale, int align_corners, float mask_threshold, int dtype,
+                            int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride,
+                            void *stream) {
+    if (!x || !flo || !out) PWC_FAIL(PWC_EINVAL, "pwc_warp_fwd: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_warp_fwd: bad shape %dx%dx%dx%d", B, C, H, W);
+    const int64_t plane = (int64_t)H * W;
+    if (x_bstride < C * plane || out_bstride < C * plane || flo_bstride < 2 * plane)
+        PWC_FAIL(PWC_EINVAL, "pwc_warp_fwd: batch stride smaller than the tensor");
+    if (x == out) PWC_FAIL(PWC_EINVAL, "pwc_warp_fwd: in-place warp is not defined");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PWC_F32:
+            return launch_warp<float>(x, flo, out, B, C, H, W, flow_scale, align_corners, mask_threshold,
+                                      x_bstride, flo_bstride, out_bstride, st);
+        case PWC_F16:
+            return launch_warp<__half>(x, flo, out, B, C, H, W, flow_scale, align_corners, mask_threshold,
+                                       x_bstride, flo_bstride, out_bstride, st);
+        default:
+            PWC_FAIL(PWC_EUNSUPPORTED, "pwc_warp_fwd: dtype %d", dtype);
+    }
+}

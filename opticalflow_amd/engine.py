@@ -1,0 +1,189 @@
+"""Execution plan of PWCDCNet.forward on one MI355X: buffers, packed weights, launch order.
+
+What the reference does per forward (models/PWCNet.py:180-273) and what the plan does instead:
+
+  * ``torch.cat((conv(x), x), 1)`` five times per level (PWCNet.py:202-264, 747 MB of copies per
+    1024x448 pair): the plan allocates ONE arena ``[B, Ctot, H, W]`` per level whose channel order
+    is the final concatenation order
+        [conv_4 | conv_3 | conv_2 | conv_1 | conv_0 | corr | c1 | up_flow | up_feat]
+    and every producer (dense convs, correlation, last pyramid conv, the two deconvs) writes its
+    channel slice in place; a consumer reads a channel *suffix* -- only the batch stride differs
+    from a dense tensor, which the C ABI takes as an argument.
+  * warp: one fused kernel instead of mesh + 2x grid_sample + mask ops (PWCNet.py:141-177), with the
+    per-level flow scale (PWCNet.py:212,226,240,256) folded in.
+  * correlation + LeakyReLU (PWCNet.py:198-199): one kernel writing straight into the arena.
+  * both images go through the feature pyramid as one 2B batch (PWCNet.py:184-195 runs it twice).
+
+All launches go to the current torch stream; nothing allocates after construction, so a plan can be
+captured into a HIP graph (``PWCDCNet.forward(..., )`` does that when ``use_graph`` is set).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+PYRAMID_CH = (3, 16, 32, 64, 96, 128, 196)
+PYRAMID_NAMES = (("conv1a", "conv1aa", "conv1b"), ("conv2a", "conv2aa", "conv2b"), ("conv3a", "conv3aa", "conv3b"),
+                 ("conv4a", "conv4aa", "conv4b"), ("conv5a", "conv5aa", "conv5b"), ("conv6aa", "conv6a", "conv6b"))
+DENSE_OUT = (128, 128, 96, 64, 32)            # conv{L}_0 .. conv{L}_4 (PWCNet.py:78-82)
+DENSE_TOTAL = sum(DENSE_OUT)                  # 448
+# channel offset of conv{L}_i's output inside the arena; conv{L}_i reads everything after it
+DENSE_OFF = (320, 192, 96, 32, 0)
+CONTEXT = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1))   # dc_conv1..6 (PWCNet.py:126-131)
+WARP_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}                      # PWCNet.py:212,226,240,256
+LEAKY = 0.1
+
+
+def level_in_channels(level: int, nd: int = 81) -> int:
+    """`od` of PWCNet.py:77,87,97,107,117."""
+    return nd if level == 6 else nd + PYRAMID_CH[level] + 4
+
+
+class PwcPlan:
+    def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device,
+                 dtype: torch.dtype = torch.float32, md: int = 4, normalize_corr: bool = False,
+                 align_corners: bool = False, conv_backend: str = "hip"):
+        if H % 64 or W % 64 or H <= 0 or W <= 0:
+            raise ValueError("PWCDCNet needs H and W to be positive multiples of 64 (got %dx%d); resize or pad the "
+                             "pair first like script_pwc.py:47-54 / inference_kitti.py:53-63" % (H, W))
+        if conv_backend not in ("hip", "torch"):
+            raise ValueError("conv_backend must be 'hip' or 'torch'")
+        if dtype != torch.float32:
+            raise NotImplementedError("plan dtype %s: only float32 is wired up" % dtype)
+        self.B, self.H, self.W = B, H, W
+        self.device, self.dtype = device, dtype
+        self.md = md
+        self.nd = (2 * md + 1) ** 2
+        self.normalize_corr = normalize_corr
+        self.align_corners = align_corners
+        self.conv_backend = conv_backend
+        self.p = params
+        kw = dict(device=device, dtype=dtype)
+
+        self.size = {l: (H >> l, W >> l) for l in range(1, 7)}
+        # pyramid scratch: per level two ping-pong buffers for the 2B batch, plus c2 (second image)
+        self.pyr_a, self.pyr_b, self.c2 = {}, {}, {}
+        for l in range(1, 7):
+            h, w = self.size[l]
+            c = PYRAMID_CH[l]
+            self.pyr_a[l] = torch.empty((2 * B, c, h, w), **kw)
+            self.pyr_b[l] = torch.empty((2 * B, c, h, w), **kw)
+        for l in range(2, 6):
+            self.c2[l] = self.pyr_a[l][B:]        # second image's level features (dense view)
+        self.warped = {l: torch.empty((B, PYRAMID_CH[l], *self.size[l]), **kw) for l in range(2, 6)}
+        self.arena = {}
+        for l in range(2, 7):
+            od = level_in_channels(l, self.nd)
+            self.arena[l] = torch.empty((B, DENSE_TOTAL + od, *self.size[l]), **kw)
+        self.flow = {l: torch.empty((B, 2, *self.size[l]), **kw) for l in range(2, 7)}
+        self.flow_out = torch.empty((B, 2, *self.size[2]), **kw)
+        h2, w2 = self.size[2]
+        self.ctx = [torch.empty((B, c, h2, w2), **kw) for c, _ in CONTEXT]
+
+        self.packed: Dict[str, torch.Tensor] = {}
+        if conv_backend == "hip":
+            for key, t in params.items():
+                if key.endswith(".weight") and t.dim() == 4 and t.shape[2:] == (3, 3):
+                    self.packed[key[:-len(".weight")]] = ops.pack_conv3x3(t)
+
+    # ---- layer primitives -----------------------------------------------------------------------
+    def _conv(self, name: str, x: torch.Tensor, out: torch.Tensor, stride: int = 1, dilation: int = 1,
+              act: bool = True, residual: Optional[torch.Tensor] = None) -> None:
+        key = name + ".0" if (name + ".0.weight") in self.p else name
+        w, b = self.p[key + ".weight"], self.p[key + ".bias"]
+        if self.conv_backend == "hip":
+            ops.conv3x3(x, self.packed[key], b, w.shape[0], stride=stride, dilation=dilation,
+                        leaky_slope=LEAKY if act else None, residual=residual, out=out)
+        else:
+            # BASELINE config[1]: convolutions by PyTorch-ROCm (MIOpen); correlation/warp stay HIP.
+            y = F.conv2d(x, w, b, stride=stride, padding=dilation, dilation=dilation)
+            if act:
+                y = F.leaky_relu(y, LEAKY)
+            if residual is not None:
+                y = y + residual
+            out.copy_(y)
+
+    def _deconv(self, name: str, x: torch.Tensor, out: torch.Tensor) -> None:
+        w, b = self.p[name + ".weight"], self.p[name + ".bias"]
+        if self.conv_backend == "hip":
+            ops.deconv4x4s2(x, w, b, out=out)
+        else:
+            out.copy_(F.conv_transpose2d(x, w, b, stride=2, padding=1))
+
+    # ---- the forward ----------------------------------------------------------------------------
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        B = self.B
+        if tuple(x.shape) != (B, 6, self.H, self.W) or x.dtype != self.dtype or x.device != self.device:
+            raise ValueError("plan built for %s %s on %s, got %s %s on %s" % (
+                (B, 6, self.H, self.W), self.dtype, self.device, tuple(x.shape), x.dtype, x.device))
+        x = ops.densify(x)
+        nd = self.nd
+        base = DENSE_TOTAL                      # first channel after the dense-block outputs
+        # -- feature pyramid, both images as one 2B batch (PWCNet.py:184-195) ----------------------
+        prev = None
+        for l in range(1, 7):
+            na, naa, nb = PYRAMID_NAMES[l - 1]
+            a, bb = self.pyr_a[l], self.pyr_b[l]
+            if l == 1:
+                self._conv(na, x[:, :3], a[:B], stride=2)
+                self._conv(na, x[:, 3:], a[B:], stride=2)
+            else:
+                self._conv(na, prev, a, stride=2)
+            self._conv(naa, a, bb)
+            self._conv(nb, bb, a)
+            if 2 <= l <= 5:
+                # level features: first image into the level's arena slot; c2 is the view a[B:]
+                # (the next level still reads the dense 2B batch in `a`)
+                c = PYRAMID_CH[l]
+                off = base + nd
+                self.arena[l][:, off:off + c].copy_(a[:B])
+            prev = a
+        # -- coarse-to-fine decoder (PWCNet.py:198-265) ---------------------------------------------
+        for l in (6, 5, 4, 3, 2):
+            ar = self.arena[l]
+            c = PYRAMID_CH[l]
+            corr_slot = ar[:, base:base + nd]
+            if l == 6:
+                ops.correlation(self.pyr_a[6][:B], self.pyr_a[6][B:], self.md, 1, self.md, 1, 1, 1.0,
+                                normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+            else:
+                off = base + nd
+                up_flow = ar[:, off + c:off + c + 2]
+                ops.warp(self.c2[l], up_flow, flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
+                         out=self.warped[l])
+                ops.correlation(ar[:, off:off + c], self.warped[l], self.md, 1, self.md, 1, 1, 1.0,
+                                normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+            lo = base
+            for i, (co, off_i) in enumerate(zip(DENSE_OUT, DENSE_OFF)):
+                self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, off_i:off_i + co])
+                lo = off_i
+            self._conv("predict_flow%d" % l, ar, self.flow[l], act=False)
+            if l > 2:
+                nxt = self.arena[l - 1]
+                cn = PYRAMID_CH[l - 1]
+                o = base + nd + cn
+                self._deconv("deconv%d" % l, self.flow[l], nxt[:, o:o + 2])
+                self._deconv("upfeat%d" % l, ar, nxt[:, o + 2:o + 4])
+        # -- context network (PWCNet.py:267-268) ------------------------------------------------------
+        t = self.arena[2]
+        for i, (_, dil) in enumerate(CONTEXT):
+            self._conv("dc_conv%d" % (i + 1), t, self.ctx[i], dilation=dil)
+            t = self.ctx[i]
+        self._conv("dc_conv7", t, self.flow_out, act=False, residual=self.flow[2])
+        return self.flow_out
+
+    def flows(self) -> Tuple[torch.Tensor, ...]:
+        """(flow2, flow3, flow4, flow5, flow6) of the last run -- the training-mode return (PWCNet.py:270-271)."""
+        return (self.flow_out, self.flow[3], self.flow[4], self.flow[5], self.flow[6])
+
+    def bytes_allocated(self) -> int:
+        tot = 0
+        for group in (self.pyr_a, self.pyr_b, self.warped, self.arena, self.flow):
+            tot += sum(t.numel() * t.element_size() for t in group.values())
+        tot += sum(t.numel() * t.element_size() for t in self.ctx + [self.flow_out])
+        tot += sum(t.numel() * t.element_size() for t in self.packed.values())
+        return tot

@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C ABI (device pointers + current HIP stream).
+
+PyTorch is used only for device memory and streams; all arithmetic happens in
+libpwc_hip.so.  Every wrapper validates what the kernels assume (device,
+dtype, dense C/H/W planes, batch stride) *before* launching -- the reference
+does no validation and silently assumes contiguous NCHW
+(correlation_cuda_kernel.cu:341-360).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (FLAG_ACT_LEAKY, FLAG_CONV_RESIDUAL, FLAG_CORR_NORMALIZE, PWC_F16, PWC_F32, PwcHipError, check)
+
+_DTYPES = {torch.float32: PWC_F32, torch.float16: PWC_F16}
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError("unsupported dtype %s (float32 / float16 only)" % t.dtype) from None
+
+
+def _plane_dense(t: torch.Tensor, name: str) -> int:
+    """Require [B,C,H,W] with dense C,H,W planes; return the batch stride in elements."""
+    if t.dim() != 4:
+        raise ValueError("%s must be 4-D [B,C,H,W], got %s" % (name, tuple(t.shape)))
+    if not t.is_cuda:
+        raise PwcHipError("%s is on %s: the HIP path needs device tensors and has no CPU fallback" % (name, t.device))
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    ok = (W == 1 or sw == 1) and (H == 1 or sh == W) and (C == 1 or sc == H * W)
+    if not ok:
+        raise ValueError("%s must have dense C,H,W planes (strides %s for shape %s)" % (name, t.stride(), tuple(t.shape)))
+    if B == 1:
+        return C * H * W
+    if sb < C * H * W:
+        raise ValueError("%s batch stride %d smaller than C*H*W" % (name, sb))
+    return sb
+
+
+def densify(t: torch.Tensor) -> torch.Tensor:
+    """Return t if its C,H,W planes are dense (batch stride free), else a contiguous copy."""
+    if t.dim() == 4:
+        B, C, H, W = t.shape
+        sb, sc, sh, sw = t.stride()
+        if (W == 1 or sw == 1) and (H == 1 or sh == W) and (C == 1 or sc == H * W) and (B == 1 or sb >= C * H * W):
+            return t
+    return t.contiguous()
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def corr_output_shape(C: int, H: int, W: int, pad_size: int, kernel_size: int, max_displacement: int,
+                      stride1: int, stride2: int) -> Tuple[int, int, int]:
+    """Shape contract of the reference binding (correlation_cuda.cc:25-38)."""
+    krad = (kernel_size - 1) // 2
+    border = krad + max_displacement
+    drad = max_displacement // stride2
+    return ((2 * drad + 1) ** 2,
+            int(math.ceil((H + 2 * pad_size - 2 * border) / float(stride1))),
+            int(math.ceil((W + 2 * pad_size - 2 * border) / float(stride1))))
+
+
+def correlation(in1: torch.Tensor, in2: torch.Tensor, pad_size: int = 4, kernel_size: int = 1,
+                max_displacement: int = 4, stride1: int = 1, stride2: int = 1, corr_multiply: float = 1.0,
+                normalize: bool = False, leaky_slope: Optional[float] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    if in1.shape != in2.shape or in1.dtype != in2.dtype or in1.device != in2.device:
+        raise ValueError("correlation inputs differ: %s/%s vs %s/%s" % (tuple(in1.shape), in1.dtype, tuple(in2.shape), in2.dtype))
+    bs1 = _plane_dense(in1, "input1")
+    bs2 = _plane_dense(in2, "input2")
+    B, C, H, W = in1.shape
+    nch, oh, ow = corr_output_shape(C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if oh <= 0 or ow <= 0:
+        raise ValueError("correlation output would be empty (%d x %d)" % (oh, ow))
+    if out is None:
+        out = torch.empty((B, nch, oh, ow), dtype=in1.dtype, device=in1.device)
+    elif tuple(out.shape) != (B, nch, oh, ow) or out.dtype != in1.dtype or out.device != in1.device:
+        raise ValueError("out must be %s %s on %s" % ((B, nch, oh, ow), in1.dtype, in1.device))
+    bso = _plane_dense(out, "out")
+    flags = (FLAG_CORR_NORMALIZE if normalize else 0) | (FLAG_ACT_LEAKY if leaky_slope is not None else 0)
+    with torch.cuda.device(in1.device):
+        rc = lib.pwc_corr_fwd(in1.data_ptr(), in2.data_ptr(), out.data_ptr(), B, C, H, W,
+                              pad_size, kernel_size, max_displacement, stride1, stride2,
+                              float(corr_multiply), _dtype_code(in1), flags, float(leaky_slope or 0.0),
+                              bs1, bs2, bso, _stream(in1))
+    check(rc, "pwc_corr_fwd")
+    return out
+
+
+def correlation_backward(in1: torch.Tensor, in2: torch.Tensor, grad_out: torch.Tensor, pad_size: int = 4,
+                         kernel_size: int = 1, max_displacement: int = 4, stride1: int = 1, stride2: int = 1,
+                         corr_multiply: float = 1.0, normalize: bool = False):
+    lib = _lib.load()
+    for name, t in (("input1", in1), ("input2", in2), ("grad_output", grad_out)):
+        _plane_dense(t, name)
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous for the backward kernel" % name)
+    B, C, H, W = in1.shape
+    g1 = torch.empty_like(in1)
+    g2 = torch.empty_like(in2)
+    with torch.cuda.device(in1.device):
+        rc = lib.pwc_corr_bwd(in1.data_ptr(), in2.data_ptr(), grad_out.data_ptr(), g1.data_ptr(), g2.data_ptr(),
+                              B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2,
+                              float(corr_multiply), _dtype_code(in1), FLAG_CORR_NORMALIZE if normalize else 0,
+                              _stream(in1))
+    check(rc, "pwc_corr_bwd")
+    return g1, g2
+
+
+def warp(x: torch.Tensor, flo: torch.Tensor, flow_scale: float = 1.0, align_corners: bool = False,
+         mask_threshold: float = 0.9999, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    bsx = _plane_dense(x, "x")
+    bsf = _plane_dense(flo, "flo")
+    B, C, H, W = x.shape
+    if tuple(flo.shape) != (B, 2, H, W) or flo.dtype != x.dtype or flo.device != x.device:
+        raise ValueError("flo must be %s %s, got %s %s" % ((B, 2, H, W), x.dtype, tuple(flo.shape), flo.dtype))
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (B, C, H, W) or out.dtype != x.dtype or out.device != x.device:
+        raise ValueError("out must match x")
+    bso = _plane_dense(out, "out")
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_warp_fwd(x.data_ptr(), flo.data_ptr(), out.data_ptr(), B, C, H, W,
+                              float(flow_scale), 1 if align_corners else 0, float(mask_threshold), _dtype_code(x),
+                              bsx, bsf, bso, _stream(x))
+    check(rc, "pwc_warp_fwd")
+    return out
+
+
+def pack_conv3x3(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] nn.Conv2d filter bank -> kernel-native packed buffer (device, float32)."""
+    lib = _lib.load()
+    if weight.dim() != 4 or weight.shape[2:] != (3, 3):
+        raise ValueError("expected [Cout,Cin,3,3], got %s" % (tuple(weight.shape),))
+    if not weight.is_cuda:
+        raise PwcHipError("weights must be on the device")
+    w = weight.detach().to(torch.float32).contiguous()
+    cout, cin = w.shape[:2]
+    nbytes = lib.pwc_conv3x3_packed_bytes(cin, cout, PWC_F32)
+    if nbytes <= 0:
+        raise PwcHipError("pwc_conv3x3_packed_bytes(%d,%d) = %d" % (cin, cout, nbytes))
+    wp = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.pwc_conv3x3_pack(w.data_ptr(), wp.data_ptr(), cin, cout, PWC_F32, _stream(w))
+    check(rc, "pwc_conv3x3_pack")
+    return wp
+
+
+def conv3x3(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cout: int, stride: int = 1,
+            dilation: int = 1, leaky_slope: Optional[float] = 0.1, residual: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    bsx = _plane_dense(x, "x")
+    B, cin, H, W = x.shape
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, cout, ho, wo), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (B, cout, ho, wo) or out.dtype != x.dtype or out.device != x.device:
+        raise ValueError("out must be %s, got %s" % ((B, cout, ho, wo), tuple(out.shape)))
+    bsy = _plane_dense(out, "out")
+    need = lib.pwc_conv3x3_packed_bytes(cin, cout, PWC_F32)
+    if wpacked.dtype != torch.float32 or wpacked.numel() * 4 != need or wpacked.device != x.device:
+        raise ValueError("packed weights do not match Cin=%d Cout=%d (have %d B, need %d B)" % (cin, cout, wpacked.numel() * 4, need))
+    if bias.dtype != torch.float32 or bias.numel() != cout or bias.device != x.device or not bias.is_contiguous():
+        raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
+    flags = FLAG_ACT_LEAKY if leaky_slope is not None else 0
+    res_ptr, bsr = 0, 0
+    if residual is not None:
+        if tuple(residual.shape) != tuple(out.shape) or residual.dtype != x.dtype:
+            raise ValueError("residual must match the output")
+        bsr = _plane_dense(residual, "residual")
+        res_ptr = residual.data_ptr()
+        flags |= FLAG_CONV_RESIDUAL
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_conv2d_fwd(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr(), res_ptr, out.data_ptr(),
+                                B, cin, H, W, cout, stride, dilation, _dtype_code(x), flags,
+                                float(leaky_slope or 0.0), bsx, bsy, bsr, _stream(x))
+    check(rc, "pwc_conv2d_fwd")
+    return out
+
+
+def deconv4x4s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.ConvTranspose2d(k=4, s=2, p=1); weight [Cin,Cout,4,4] float32 contiguous."""
+    lib = _lib.load()
+    bsx = _plane_dense(x, "x")
+    B, cin, H, W = x.shape
+    if weight.dim() != 4 or weight.shape[0] != cin or weight.shape[2:] != (4, 4) or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous [Cin=%d,Cout,4,4], got %s" % (cin, tuple(weight.shape)))
+    cout = weight.shape[1]
+    if out is None:
+        out = torch.empty((B, cout, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (B, cout, 2 * H, 2 * W):
+        raise ValueError("out must be %s" % ((B, cout, 2 * H, 2 * W),))
+    bsy = _plane_dense(out, "out")
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_deconv4x4s2_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                     B, cin, H, W, cout, _dtype_code(x), bsx, bsy, _stream(x))
+    check(rc, "pwc_deconv4x4s2_fwd")
+    return out

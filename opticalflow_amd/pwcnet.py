@@ -1,0 +1,184 @@
+"""PWCDCNet with the reference's constructor, state-dict and forward()/warp() surface, executed by
+hand-written gfx950 kernels (libpwc_hip.so) instead of cuDNN + the CUDA correlation extension.
+
+Reference: ``models/PWCNet.py:40-273`` (class), ``:497-506`` (factory ``pwc_dc_net``).
+
+The module owns ordinary ``nn.Conv2d`` / ``nn.ConvTranspose2d`` children purely as parameter
+containers, registered under the reference's names and in the reference's order, so
+
+  * ``state_dict()`` has the reference's 128 keys (``conv1a.0.weight`` ... ``dc_conv7.bias``,
+    including the never-used ``deconv2.*``, PWCNet.py:124) and ``load_state_dict(strict=True)``
+    accepts a reference ``.pth.tar`` unchanged;
+  * ``forward(x: [B,6,H,W]) -> flow2: [B,2,H/4,W/4]`` in eval mode, the 5-tuple
+    ``(flow2, flow3, flow4, flow5, flow6)`` in training mode (PWCNet.py:270-273);
+  * ``warp(x, flo)`` is the fused HIP warp.
+
+Additive constructor keywords: ``normalize_corr`` / ``align_corners`` (SURVEY.md section 0, facts 3
+and 4: defaults reproduce the reference as executed on a current torch; set both True for the
+semantics the published weights were trained with), ``conv_backend`` ('hip' = MFMA implicit-GEMM
+kernels, 'torch' = BASELINE config[1], convolutions left to PyTorch-ROCm), ``use_graph``.
+
+Inference only: the HIP path does not build an autograd graph (returned flows have
+``requires_grad=False``).  Tensors must live on a ROCm device; there is no CPU execution path.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import PwcHipError
+from .correlation import Correlation
+from .engine import CONTEXT, DENSE_OUT, PYRAMID_CH, PYRAMID_NAMES, PwcPlan, level_in_channels
+from .weights import load_checkpoint, synthetic_state_dict
+
+__all__ = ["PWCDCNet", "pwc_dc_net"]
+
+
+def _conv_block(cin: int, cout: int, stride: int = 1, dilation: int = 1) -> nn.Sequential:
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, stride=stride, padding=dilation, dilation=dilation, bias=True),
+                         nn.LeakyReLU(0.1))
+
+
+class PWCDCNet(nn.Module):
+    def __init__(self, md: int = 4, normalize_corr: bool = False, align_corners: bool = False,
+                 conv_backend: str = "hip", use_graph: bool = False):
+        super().__init__()
+        self.md = md
+        self.normalize_corr = normalize_corr
+        self.align_corners = align_corners
+        self.conv_backend = conv_backend
+        self.use_graph = use_graph
+
+        # registration order == reference order (PWCNet.py:52-132)
+        for lvl, (na, naa, nb) in enumerate(PYRAMID_NAMES, start=1):
+            cin, cout = PYRAMID_CH[lvl - 1], PYRAMID_CH[lvl]
+            self.add_module(na, _conv_block(cin, cout, stride=2))
+            self.add_module(naa, _conv_block(cout, cout))
+            self.add_module(nb, _conv_block(cout, cout))
+        self.corr = Correlation(pad_size=md, kernel_size=1, max_displacement=md, stride1=1, stride2=1,
+                                corr_multiply=1, normalize=normalize_corr)
+        self.leakyRELU = nn.LeakyReLU(0.1)
+        nd = (2 * md + 1) ** 2
+        for lvl in (6, 5, 4, 3, 2):
+            od = level_in_channels(lvl, nd)
+            grown = od
+            for i, cout in enumerate(DENSE_OUT):
+                self.add_module("conv%d_%d" % (lvl, i), _conv_block(grown, cout))
+                grown += cout
+            self.add_module("predict_flow%d" % lvl, nn.Conv2d(grown, 2, 3, padding=1, bias=True))
+            self.add_module("deconv%d" % lvl, nn.ConvTranspose2d(2, 2, 4, 2, 1, bias=True))
+            if lvl > 2:
+                self.add_module("upfeat%d" % lvl, nn.ConvTranspose2d(grown, 2, 4, 2, 1, bias=True))
+        cin = level_in_channels(2, nd) + sum(DENSE_OUT)
+        for i, (cout, dil) in enumerate(CONTEXT, start=1):
+            self.add_module("dc_conv%d" % i, _conv_block(cin, cout, dilation=dil))
+            cin = cout
+        self.dc_conv7 = nn.Conv2d(cin, 2, 3, padding=1, bias=True)
+
+        # same initialisation as the reference (PWCNet.py:134-138)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight.data, mode="fan_in")
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+        self._plans: Dict[Tuple, PwcPlan] = {}
+        self._graphs: Dict[Tuple, Tuple] = {}
+        self._versions: Optional[Tuple[int, ...]] = None
+
+    # ---- reference surface --------------------------------------------------------------------
+    def warp(self, x: torch.Tensor, flo: torch.Tensor) -> torch.Tensor:
+        """warp an image/tensor (im2) back to im1 according to the optical flow (PWCNet.py:141-177)."""
+        return ops.warp(ops.densify(x), ops.densify(flo), 1.0, self.align_corners)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor):
+        if x.dim() != 4 or x.shape[1] != 6:
+            raise ValueError("expected [B,6,H,W] (two stacked 3-channel images), got %s" % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise PwcHipError("PWCDCNet.forward needs a tensor on the ROCm device (got %s): the HIP path has no "
+                              "CPU fallback" % x.device)
+        plan = self._plan_for(x)
+        key = self._key(x)
+        if self.use_graph and not self.training:
+            out = self._run_graph(key, plan, x)
+        else:
+            out = plan.run(x)
+        if self.training:
+            return tuple(t.clone() for t in plan.flows())
+        return out.clone()
+
+    # ---- plan management -----------------------------------------------------------------------
+    def _key(self, x):
+        return (x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device, self.conv_backend,
+                self.normalize_corr, self.align_corners)
+
+    def _param_versions(self):
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def invalidate_plans(self):
+        self._plans.clear()
+        self._graphs.clear()
+        self._versions = None
+
+    def _plan_for(self, x) -> PwcPlan:
+        ver = self._param_versions()
+        if ver != self._versions:
+            self.invalidate_plans()
+            self._versions = ver
+        key = self._key(x)
+        plan = self._plans.get(key)
+        if plan is None:
+            params = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
+            for k, v in params.items():
+                if v.device != x.device:
+                    raise PwcHipError("parameter %s is on %s but the input is on %s: call net.to(device) first"
+                                      % (k, v.device, x.device))
+                if v.dtype != torch.float32:
+                    raise NotImplementedError("parameters must be float32 (got %s for %s)" % (v.dtype, k))
+            plan = PwcPlan(params, x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype, self.md,
+                           self.normalize_corr, self.align_corners, self.conv_backend)
+            self._plans[key] = plan
+        return plan
+
+    def _run_graph(self, key, plan: PwcPlan, x: torch.Tensor) -> torch.Tensor:
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_in = torch.empty_like(x, memory_format=torch.contiguous_format)
+            static_in.copy_(x)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):           # warm-up outside capture (first-launch attributes)
+                plan.run(static_in)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                plan.run(static_in)
+            entry = (graph, static_in)
+            self._graphs[key] = entry
+        graph, static_in = entry
+        static_in.copy_(x)
+        graph.replay()
+        return plan.flow_out
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_plans()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        self.invalidate_plans()
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
+    def manifest(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        return [(k, tuple(v.shape)) for k, v in self.state_dict().items()]
+
+
+def pwc_dc_net(path: Optional[str] = None, **kwargs) -> PWCDCNet:
+    """Factory with the reference's name and argument (PWCNet.py:497-506)."""
+    model = PWCDCNet(**kwargs)
+    if path is not None:
+        model.load_state_dict(load_checkpoint(path))
+    return model

@@ -1,0 +1,288 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden fixtures.  Needs an MI355X: run with ``-m gpu``.
+
+Tolerances (fp32 kernels, fp32 accumulation; summation order differs from the CPU):
+  * correlation / conv: |err| <= 2e-6 * sqrt(K) * scale, K = reduction length
+  * warp: 2e-6 absolute on O(1) data, identical mask decisions
+  * full forward: mean EPE on raw flow2 <= 1e-3 vs the reference's fp32 AND fp64 outputs
+    (BASELINE.json north_star bar); observed values are printed.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, seeded_rand
+from oracle import pwc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(gpu_device):
+    from opticalflow_amd import _lib
+    _lib.load()          # fail loudly if the HIP library is missing
+    return gpu_device
+
+
+# ------------------------------------------------------------------ correlation
+def test_corr_golden_fast_and_scalar_paths(dev):
+    from opticalflow_amd import ops
+    g = load_golden("g1_corr.npz")
+    for i in range(int(g["n"])):
+        shp = g["shape_%d" % i]
+        a = seeded_rand(shp, 100 + i, -1, 1)
+        b = seeded_rand(shp, 200 + i, -1, 1)
+        ref = torch.from_numpy(g["out_%d" % i])
+        got = ops.correlation(a.to(dev), b.to(dev), 4, 1, 4, 1, 1, 1.0).cpu()
+        tol = 2e-6 * float(shp[1]) ** 0.5 * max(1.0, ref.abs().max().item())
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= tol, (tuple(shp), (got - ref).abs().max().item())
+        gotn = ops.correlation(a.to(dev), b.to(dev), 4, 1, 4, 1, 1, 1.0, normalize=True).cpu()
+        assert torch.allclose(gotn, ref / float(shp[1]), rtol=1e-5, atol=1e-6)
+
+
+def test_corr_generic_path_stride2_multiply(dev):
+    from opticalflow_amd import ops
+    g = load_golden("g1_corr.npz")
+    a = seeded_rand((1, 6, 10, 12), 300, -1, 1).to(dev)
+    b = seeded_rand((1, 6, 10, 12), 301, -1, 1).to(dev)
+    got = ops.correlation(a, b, 4, 1, 4, 1, 2, 3.0).cpu()
+    assert torch.allclose(got, torch.from_numpy(g["s2_out"]), rtol=1e-5, atol=1e-5)
+    # kernel_size 3 / stride1 2 against the oracle's statement of the CUDA semantics
+    a = seeded_rand((2, 4, 15, 17), 310, -1, 1)
+    b = seeded_rand((2, 4, 15, 17), 311, -1, 1)
+    ref = O.correlation(a, b, 3, 3, 6, 2, 2, 1, normalize=True)
+    got = ops.correlation(a.to(dev), b.to(dev), 3, 3, 6, 2, 2, 1.0, normalize=True).cpu()
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_corr_leaky_fused_into_arena_slot(dev):
+    from opticalflow_amd import ops
+    B, C, H, W = 2, 32, 24, 64
+    a = seeded_rand((B, C, H, W), 1, -1, 1)
+    b = seeded_rand((B, C, H, W), 2, -1, 1)
+    arena = torch.full((B, 200, H, W), 7.0, device=dev)
+    arena[:, 100:100 + C] = a.to(dev)                     # in1 is itself an arena slice (batch-strided)
+    ops.correlation(arena[:, 100:100 + C], b.to(dev), 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1, out=arena[:, 10:91])
+    ref = O.leaky_relu(O.correlation(a, b, 4, 1, 4, 1, 1, 1))
+    assert (arena[:, 10:91].cpu() - ref).abs().max().item() < 2e-5
+    assert (arena[:, :10] == 7).all() and (arena[:, 91:100] == 7).all() and (arena[:, 132:] == 7).all()
+
+
+def test_corr_properties_full_size(dev):
+    """Size-independent properties at the BASELINE level-2 geometry (B=4, C=32, 112x256)."""
+    from opticalflow_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.randn(4, 32, 112, 256, generator=g).to(dev)
+    b = torch.randn(4, 32, 112, 256, generator=g).to(dev)
+    c = ops.correlation(a, b)
+    # bilinearity
+    assert torch.allclose(ops.correlation(2 * a, b), 2 * c, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(ops.correlation(a, b + b), 2 * c, rtol=1e-5, atol=1e-4)
+    # centre channel == plain channel dot product
+    assert torch.allclose(c[:, 40], (a * b).sum(1), rtol=1e-4, atol=1e-3)
+    # symmetry: corr(a,b)[d](p) == corr(b,a)[-d](p+d): check d=(dy=-4,dx=+4) <-> (+4,-4)
+    cba = ops.correlation(b, a)
+    ch, chm = 0 * 9 + 8, 8 * 9 + 0
+    assert torch.allclose(c[:, ch, 4:, :-4], cba[:, chm, :-4, 4:], rtol=1e-4, atol=1e-3)
+    # out-of-image displacements are exactly zero
+    assert (c[:, 0, :4, :] == 0).all() and (c[:, 80, -4:, :] == 0).all()
+
+
+def test_corr_backward_matches_autograd_of_oracle(dev):
+    from opticalflow_amd import ops
+    a = seeded_rand((2, 6, 9, 11), 20, -1, 1).requires_grad_(True)
+    b = seeded_rand((2, 6, 9, 11), 21, -1, 1).requires_grad_(True)
+    go = seeded_rand((2, 81, 9, 11), 22, -1, 1)
+    O.correlation(a, b, 4, 1, 4, 1, 1, 1).backward(go)
+    g1, g2 = ops.correlation_backward(a.detach().to(dev), b.detach().to(dev), go.to(dev))
+    assert torch.allclose(g1.cpu(), a.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(g2.cpu(), b.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_correlation_module_and_pybind_shim(dev):
+    import correlation_cuda
+    from opticalflow_amd import Correlation
+    a = seeded_rand((1, 16, 16, 32), 30, -1, 1).to(dev)
+    b = seeded_rand((1, 16, 16, 32), 31, -1, 1).to(dev)
+    m = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
+    y = m(a, b)
+    ref = O.correlation(a.cpu(), b.cpu(), 4, 1, 4, 1, 1, 1)
+    assert torch.allclose(y.cpu(), ref, rtol=1e-5, atol=1e-5)
+    # pybind-compatible entry point: empty output tensor, normalised (CUDA kernel) semantics
+    out = a.new_empty(0)
+    assert correlation_cuda.forward(a, b, a.new_empty(0), b.new_empty(0), out, 4, 1, 4, 1, 1, 1) == 1
+    assert torch.allclose(out.cpu(), ref / 16.0, rtol=1e-5, atol=1e-6)
+    # autograd through the module
+    a2 = a.clone().requires_grad_(True)
+    m(a2, b).sum().backward()
+    ar = a.cpu().clone().requires_grad_(True)
+    O.correlation(ar, b.cpu(), 4, 1, 4, 1, 1, 1).sum().backward()
+    assert torch.allclose(a2.grad.cpu(), ar.grad, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ warp
+def test_warp_golden(dev):
+    from opticalflow_amd import ops
+    g = load_golden("g2_warp.npz")
+    for name in g["names"]:
+        x = torch.from_numpy(g["x_" + name])
+        flo = torch.from_numpy(g["flo_" + name])
+        ref = torch.from_numpy(g["out_" + name])
+        got = ops.warp(x.to(dev), flo.to(dev)).cpu()
+        assert ((got == 0) == (ref == 0)).float().mean().item() > 0.999, name
+        assert (got - ref).abs().max().item() < 3e-6, (name, (got - ref).abs().max().item())
+
+
+def test_warp_scale_align_and_strided_operands(dev):
+    from opticalflow_amd import ops
+    B, C, H, W = 2, 9, 14, 32
+    x = seeded_rand((B, C, H, W), 40, -1, 1)
+    flo = seeded_rand((B, 2, H, W), 41, -3, 3)
+    for ac in (False, True):
+        ref = O.warp(x, flo * 2.5, align_corners=ac)
+        arena = torch.zeros((B, 20, H, W), device=dev)
+        arena[:, 5:7] = flo.to(dev)
+        out = torch.zeros((B, 30, H, W), device=dev)
+        ops.warp(x.to(dev), arena[:, 5:7], flow_scale=2.5, align_corners=ac, out=out[:, 3:3 + C])
+        assert (out[:, 3:3 + C].cpu() - ref).abs().max().item() < 3e-6
+        assert (out[:, :3] == 0).all() and (out[:, 3 + C:] == 0).all()
+    # zero flow with align_corners=True is the identity
+    idt = ops.warp(x.to(dev), torch.zeros(B, 2, H, W, device=dev), align_corners=True).cpu()
+    assert (idt - x).abs().max().item() < 1e-5      # (x*2/(W-1)-1+1)/2*(W-1) is x only up to fp32 rounding
+
+
+def test_model_warp_method(dev):
+    from opticalflow_amd import PWCDCNet
+    net = PWCDCNet()
+    x = seeded_rand((1, 4, 8, 16), 50, -1, 1)
+    flo = seeded_rand((1, 2, 8, 16), 51, -2, 2)
+    assert (net.warp(x.to(dev), flo.to(dev)).cpu() - O.warp(x, flo)).abs().max().item() < 3e-6
+
+
+# ------------------------------------------------------------------ conv / deconv
+CONV_CASES = [
+    # (B, Cin, Cout, H, W, stride, dilation)
+    (2, 3, 16, 64, 64, 2, 1),
+    (1, 16, 16, 32, 96, 1, 1),
+    (2, 32, 64, 16, 32, 2, 1),
+    (1, 128, 196, 14, 32, 2, 1),
+    (1, 196, 196, 7, 16, 1, 1),
+    (1, 81, 128, 7, 16, 1, 1),
+    (1, 565, 128, 16, 32, 1, 1),
+    (1, 128, 128, 24, 40, 1, 2),
+    (1, 128, 128, 24, 40, 1, 4),
+    (1, 128, 96, 24, 40, 1, 8),
+    (1, 96, 64, 40, 72, 1, 16),
+    (1, 64, 32, 9, 33, 1, 1),
+    (2, 597, 2, 14, 32, 1, 1),
+    (1, 32, 2, 16, 32, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_vs_torch_cpu(dev, case):
+    from opticalflow_amd import ops
+    B, cin, cout, H, W, stride, dil = case
+    x = seeded_rand((B, cin, H, W), 60, -1, 1)
+    w = seeded_rand((cout, cin, 3, 3), 61, -1, 1) * (2.0 / (cin * 9)) ** 0.5
+    bias = seeded_rand((cout,), 62, -0.5, 0.5)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=dil, dilation=dil), 0.1)
+    wp = ops.pack_conv3x3(w.to(dev))
+    got = ops.conv3x3(x.to(dev), wp, bias.to(dev), cout, stride=stride, dilation=dil, leaky_slope=0.1).cpu()
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 3e-6 * (cin * 9) ** 0.5, (case, err)
+
+
+def test_conv3x3_arena_slices_residual_no_act(dev):
+    from opticalflow_amd import ops
+    B, H, W = 2, 16, 32
+    arena = torch.zeros((B, 300, H, W), device=dev)
+    xin = seeded_rand((B, 200, H, W), 70, -1, 1)
+    arena[:, 100:] = xin.to(dev)
+    w = seeded_rand((64, 200, 3, 3), 71, -1, 1) * 0.03
+    bias = seeded_rand((64,), 72, -0.5, 0.5)
+    ops.conv3x3(arena[:, 100:], ops.pack_conv3x3(w.to(dev)), bias.to(dev), 64, out=arena[:, 36:100])
+    ref = F.leaky_relu(F.conv2d(xin, w, bias, padding=1), 0.1)
+    assert (arena[:, 36:100].cpu() - ref).abs().max().item() < 1e-4
+    assert (arena[:, :36] == 0).all()
+    assert torch.equal(arena[:, 100:].cpu(), xin)
+    # 2-channel head, no activation, residual add (flow2 + dc_conv7(...), PWCNet.py:268)
+    w2 = seeded_rand((2, 64, 3, 3), 73, -1, 1) * 0.05
+    b2 = seeded_rand((2,), 74, -0.5, 0.5)
+    res = seeded_rand((B, 2, H, W), 75, -1, 1)
+    got = ops.conv3x3(arena[:, 36:100], ops.pack_conv3x3(w2.to(dev)), b2.to(dev), 2, leaky_slope=None,
+                      residual=res.to(dev)).cpu()
+    ref2 = F.conv2d(ref, w2, b2, padding=1) + res
+    assert (got - ref2).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("cin", [2, 529, 597])
+def test_deconv_vs_torch_cpu(dev, cin):
+    from opticalflow_amd import ops
+    B, H, W = 2, 7, 16
+    x = seeded_rand((B, cin, H, W), 80, -1, 1)
+    w = seeded_rand((cin, 2, 4, 4), 81, -1, 1) * (2.0 / (2 * 16)) ** 0.5 * (0.1 if cin > 2 else 1.0)
+    b = seeded_rand((2,), 82, -0.5, 0.5)
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    out = torch.zeros((B, 6, 2 * H, 2 * W), device=dev)
+    ops.deconv4x4s2(x.to(dev), w.to(dev), b.to(dev), out=out[:, 2:4])
+    assert (out[:, 2:4].cpu().double() - ref).abs().max().item() < 3e-6 * (cin * 4) ** 0.5 * 4
+    assert (out[:, :2] == 0).all() and (out[:, 4:] == 0).all()
+
+
+# ------------------------------------------------------------------ full forward
+def _golden_net(dev, **kw):
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    g = load_golden("g3_forward.npz")
+    net = PWCDCNet(**kw)
+    sd = synthetic_state_dict(net.manifest(), seed=int(g["wseed"]), gain=float(g["gain"]), bias_std=float(g["bias_std"]))
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev).eval(), g
+
+
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+def test_forward_golden_epe(dev, backend):
+    net, g = _golden_net(dev, conv_backend=backend)
+    for tag in ("s", "m"):
+        x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag]).to(dev)
+        f2 = net(x).cpu()
+        ref32 = torch.from_numpy(g["flow2_" + tag])
+        ref64 = torch.from_numpy(g["flow2_f64_" + tag])
+        e32, e64 = O.epe(f2, ref32), O.epe(f2, ref64)
+        print("forward[%s,%s]: EPE vs ref fp32 %.3e, vs ref fp64 %.3e (oracle fp32-vs-fp64 %.3e)"
+              % (backend, tag, e32, e64, O.epe(ref32, ref64)))
+        assert f2.shape == ref32.shape
+        assert e32 < 1e-3 and e64 < 1e-3
+
+
+def test_forward_training_tuple_and_graph(dev):
+    net, g = _golden_net(dev)
+    x = seeded_rand(g["xshape_m"], g["xseed_m"]).to(dev)
+    net.train()
+    outs = net(x)
+    assert len(outs) == 5
+    for lvl, o in zip((2, 3, 4, 5, 6), outs):
+        assert O.epe(o.cpu(), torch.from_numpy(g["train_flow%d_m" % lvl])) < 1e-3, lvl
+    net.eval()
+    eager = net(x)
+    net.use_graph = True
+    a = net(x)
+    b = net(x * 0.5)
+    c = net(x)
+    assert torch.equal(a, eager) and torch.equal(a, c) and not torch.equal(a, b)
+
+
+def test_forward_rejects_bad_inputs(dev):
+    from opticalflow_amd import PWCDCNet, PwcHipError
+    net = PWCDCNet().to(dev).eval()
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 6, 100, 128, device=dev))          # not a multiple of 64
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 3, 64, 64, device=dev))
+    with pytest.raises(PwcHipError):
+        net(torch.zeros(1, 6, 64, 64))                         # CPU tensor: no fallback

@@ -1,0 +1,105 @@
+"""Pin the CPU oracle (oracle/pwc_oracle.py) against fixtures produced by the reference's own Python
+(oracle/gen_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, seeded_rand
+from oracle import pwc_oracle as O
+from opticalflow_amd.weights import synthetic_state_dict
+
+
+def _digest(t):
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def test_g1_correlation_unnormalised_matches_reference():
+    g = load_golden("g1_corr.npz")
+    for i in range(int(g["n"])):
+        shp = g["shape_%d" % i]
+        a = seeded_rand(shp, 100 + i, -1, 1)
+        b = seeded_rand(shp, 200 + i, -1, 1)
+        assert _digest(a) + _digest(b) == str(g["digest_%d" % i]), "input recipe drifted"
+        ref = torch.from_numpy(g["out_%d" % i])
+        got = O.correlation(a, b, 4, 1, 4, 1, 1, 1)
+        assert got.shape == ref.shape
+        tol = 2e-6 * shp[1] ** 0.5 + 1e-6
+        assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        # normalised (CUDA-kernel) semantics = fallback / C   (correlation_cuda_kernel.cu:104,143)
+        gotn = O.correlation(a, b, 4, 1, 4, 1, 1, 1, normalize=True)
+        assert torch.allclose(gotn, ref / shp[1], rtol=1e-5, atol=1e-6)
+
+
+def test_g1_loop_statement_agrees():
+    a = seeded_rand((1, 5, 6, 7), 1, -1, 1)
+    b = seeded_rand((1, 5, 6, 7), 2, -1, 1)
+    loops = O.correlation_loops(a.numpy(), b.numpy())
+    vec = O.correlation(a.double(), b.double(), 4, 1, 4, 1, 1, 1).numpy()
+    assert np.abs(loops - vec).max() < 1e-12
+
+
+def test_g1_stride2_multiply():
+    g = load_golden("g1_corr.npz")
+    a = seeded_rand((1, 6, 10, 12), 300, -1, 1)
+    b = seeded_rand((1, 6, 10, 12), 301, -1, 1)
+    got = O.correlation(a, b, 4, 1, 4, 1, 2, 3)
+    ref = torch.from_numpy(g["s2_out"])
+    assert got.shape == ref.shape == (1, 25, 10, 12)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_g2_warp_matches_reference():
+    g = load_golden("g2_warp.npz")
+    for name in g["names"]:
+        x = torch.from_numpy(g["x_" + name])
+        flo = torch.from_numpy(g["flo_" + name])
+        ref = torch.from_numpy(g["out_" + name])
+        got = O.warp(x, flo)
+        # mask decisions must agree exactly; values to fp32 rounding
+        assert ((got == 0) == (ref == 0)).float().mean().item() > 0.999, name
+        assert (got - ref).abs().max().item() < 2e-6, name
+        ref64 = torch.from_numpy(g["out64_" + name])
+        got64 = O.warp(x.double(), flo.double())
+        assert (got64 - ref64).abs().max().item() < 1e-12, name
+
+
+def test_g3_forward_matches_reference():
+    g = load_golden("g3_forward.npz")
+    sd = synthetic_state_dict(O.state_dict_manifest(), seed=int(g["wseed"]), gain=float(g["gain"]),
+                              bias_std=float(g["bias_std"]))
+    blob = b"".join(sd[k].numpy().tobytes() for k, _ in O.state_dict_manifest())
+    assert hashlib.sha256(blob).hexdigest() == str(g["weights_digest"]), "weight recipe drifted"
+    torch.set_num_threads(8)
+    for tag in ("s", "m"):
+        x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag])
+        assert _digest(x) == str(g["xdigest_" + tag])
+        with torch.no_grad():
+            outs = O.pwc_forward(sd, x, all_levels=True)
+        ref2 = torch.from_numpy(g["flow2_" + tag])
+        assert O.epe(outs[0], ref2) < 1e-5
+        for lvl, o in zip((2, 3, 4, 5, 6), outs):
+            ref = torch.from_numpy(g["train_flow%d_%s" % (lvl, tag)])
+            assert o.shape == ref.shape
+            assert O.epe(o, ref) < 1e-5, (tag, lvl)
+        # fp64 truth
+        assert O.epe(outs[0], torch.from_numpy(g["flow2_f64_" + tag])) < 1e-4
+
+
+def test_g4_flo_bytes():
+    g = load_golden("g4_flo.npz")
+    uv, blob = g["uv"], g["blob"].tobytes()
+    assert O.flo_bytes(uv) == blob
+    assert np.array_equal(O.parse_flo(blob), uv)
+    assert blob[:4] == b"PIEH"
+    with pytest.raises(ValueError):
+        O.parse_flo(b"XXXX" + blob[4:])
+
+
+def test_g5_manifest():
+    g = load_golden("g5_manifest.npz")
+    man = O.state_dict_manifest()
+    assert [k for k, _ in man] == [str(k) for k in g["keys"]]
+    assert [",".join(map(str, s)) for _, s in man] == [str(s) for s in g["shapes"]]
+    assert len(man) == 128 and sum(int(np.prod(s)) for _, s in man) == 9374340
