@@ -57,6 +57,27 @@ def conv_macs_per_pair(H, W):
     return total
 
 
+def log(msg):
+    """Progress to stderr (the JSON line on stdout stays alone)."""
+    print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def host_cores():
+    """CPU threads this process may really use: min(affinity, cgroup quota) -- a GPU box exposes the
+    whole host in sched_getaffinity but caps the container's CPU share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("PWC_BENCH_CPU_THREADS", "16"))))
+
+
 def event_time_ms(fn, reps, stream):
     """Average duration of fn() over `reps` back-to-back launches, HIP events on the launch stream."""
     start = torch.cuda.Event(enable_timing=True)
@@ -124,8 +145,12 @@ def main():
             return gather_flows(flow, counts, dst=0)
         return flow
 
-    for _ in range(args.warmup):
+    log("rank %d/%d: net on %s, batch %d x 6x%dx%d resident; warm-up x%d" % (rank, world, dev, B, H, W, args.warmup))
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log("warm-up step %d done" % i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -138,6 +163,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        log("timed region: %d steps in %.3f s" % (args.steps, elapsed))
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,6 +225,7 @@ def main():
                                    "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4)}
 
         # ---- parity spot check + CPU baseline (the oracle is the checker / the baseline, never the product)
+        log("roofline probes done; parity spot check")
         from oracle import pwc_oracle as O
         sd_cpu = {k: v.detach().cpu() for k, v in net.state_dict().items()}
         xs = torch.rand(1, 6, 64, 128, generator=torch.Generator().manual_seed(7))
@@ -205,8 +233,9 @@ def main():
             ref = O.pwc_forward(sd_cpu, xs)
         result["epe_vs_cpu_oracle_64x128"] = float("%.3e" % O.epe(net(xs.to(dev)).cpu(), ref))
         if world == 1 and not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = host_cores()
             torch.set_num_threads(cores)
+            log("cpu baseline: oracle forward at 1x6x%dx%d on %d threads for ~%.0f s" % (H, W, cores, args.cpu_seconds))
             xc = torch.rand(1, 6, H, W, generator=torch.Generator().manual_seed(1234))
             with torch.no_grad():
                 O.pwc_forward(sd_cpu, xc)
