@@ -1,0 +1,295 @@
+// 3x3 convolution as an im2col-free implicit GEMM on the gfx950 matrix cores -- kernel template.
+// Included by one translation unit per (stride, dilation) so the instantiations build in parallel.
+//
+// GEMM view (fp32 in, fp32 accumulate; v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain):
+//     Y[cout, pixel] = bias[cout] + sum_{cin,ky,kx} Wt[cout,(cin,ky,kx)] * X[cin, y*s + ky*d - d, x*s + kx*d - d]
+//   A operand = weights (lane l holds A[cout = l&31][k = l>>5]),  B operand = input (B[k = l>>5][pixel = l&31]),
+//   D = 32 cout x 32 pixel with the pixel on the lane -> every store instruction writes 128-byte row
+//   segments of the NCHW output.  The two k of one MFMA are the channel pair (2cp, 2cp+1) at one tap, so
+//   both operands are ds_read_b32 of 32 consecutive dwords per half-wave (conflict-free).
+//
+// Workgroup = 4 waves, one per SIMD, one workgroup per CU (the accumulators may use the whole 512-entry
+// register file).  Tile = (4*NT rows x 32 cols) pixels x (32*MT) couts; wave w owns rows w*NT..w*NT+NT-1.
+// Cin is consumed in chunks of 8 through a DOUBLE-BUFFERED LDS image
+//     input tile  [8][rows+halo][cols+halo]   flat, dword granular      (tap = address offset: no im2col)
+//     weights     [8][9 taps][32*MT couts]                               (from the packed [chunk][c][tap][CoutP])
+// filled ONLY by buffer_load ... lds (LDS-DMA): no staging VGPRs, no VALU in the loop.  Each lane's source
+// offset is computed once per workgroup; zero padding, ragged image edges and the ragged last channel
+// chunk all come from the buffer range check (out-of-range lanes deliver 0 to LDS).  Chunk k+1 streams in
+// while chunk k's 36*MT*NT MFMAs run; one barrier per chunk.
+#pragma once
+#include "pwc_common.h"
+
+namespace pwc_conv {
+
+using pwc::from_f32;
+using pwc::leaky;
+using pwc::to_f32;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kCK = 8;            // input channels per chunk
+constexpr int kThreads = 256;     // 4 waves
+constexpr int kTileW = 32;        // = MFMA N
+constexpr unsigned kOOB = 0x80000000u;   // voffset that always fails the range check -> LDS gets 0
+constexpr int kRsrcFlags = 0x00020000;   // raw buffer, 32-bit elements irrelevant (offen addressing)
+
+__device__ __forceinline__ void *uniform_ptr(const void *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
+}
+
+template <int MT, int NT, int S, int D>
+struct Geom {
+    static constexpr int kTileH = 4 * NT;
+    static constexpr bool kRowSep = (D >= 16);                      // stage the three ky row-sets separately
+    static constexpr int kInW = (kTileW - 1) * S + 2 * D + 1;
+    static constexpr int kInH = kRowSep ? 3 * kTileH : (kTileH - 1) * S + 2 * D + 1;
+    static constexpr int kCH = kInH * kInW;                          // floats per staged channel (flat)
+    static constexpr int kKyStride = kRowSep ? kTileH * kInW : D * kInW;
+    static constexpr int kInElems = kCK * kCH;
+    static constexpr int kInSlots = (kInElems + kThreads - 1) / kThreads;       // dword DMAs per thread per chunk
+    static constexpr int kInRegion = kInSlots * kThreads;                         // floats
+    static constexpr int kCoutT = 32 * MT;
+    static constexpr int kWPieces = kCK * 9 * kCoutT / 4;                         // 16-byte pieces per chunk
+    static constexpr int kWSlots = (kWPieces + kThreads - 1) / kThreads;
+    static constexpr int kWRegion = kWSlots * kThreads * 4;                       // floats
+    static constexpr int kBufFloats = kInRegion + kWRegion;
+    static constexpr int kSmemBytes = 2 * kBufFloats * 4;
+    static_assert(kSmemBytes <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    static_assert(MT * NT <= 16, "accumulators exceed the register file");
+};
+
+namespace {   // kernels and launchers have internal linkage: each translation unit owns its instantiations
+
+// Start the LDS-DMA of one 8-channel chunk (input tile + weight slab) into `buf`.
+template <class G>
+__device__ __forceinline__ void issue_chunk(const float *xb, const float *wg, int chunk, int Cin, int plane,
+                                            int64_t wchunk, unsigned wbytes, int wave, float *buf,
+                                            const unsigned (&in_off)[G::kInSlots], const unsigned (&w_off)[G::kWSlots]) {
+    const int c0 = chunk * kCK;
+    const int cvalid = min(kCK, Cin - c0);
+    // descriptors built from readfirstlane'd words so hipcc can prove them wave-uniform
+    // (otherwise every DMA is wrapped in a waterfall loop)
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(xb + (int64_t)c0 * plane), 0, __builtin_amdgcn_readfirstlane(cvalid * plane * 4), kRsrcFlags);
+    float *dst_in = buf + wave * 64;
+#pragma unroll
+    for (int j = 0; j < G::kInSlots; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(dst_in + j * kThreads), 4, in_off[j], 0, 0, 0);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        uniform_ptr(wg + (int64_t)chunk * wchunk), 0, __builtin_amdgcn_readfirstlane((int)wbytes), kRsrcFlags);
+    float *dst_w = buf + G::kInRegion + wave * 256;
+#pragma unroll
+    for (int j = 0; j < G::kWSlots; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dst_w + j * kThreads * 4), 16, w_off[j], 0, 0, 0);
+}
+
+template <int MT, int NT, int S, int D>
+__global__ void __launch_bounds__(kThreads, 1)
+conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+                    const float *__restrict__ residual, float *__restrict__ y,
+                    int Cin, int H, int W, int Cout, int CoutP, int Ho, int Wo, int tiles_x, int tiles_y,
+                    int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky) {
+    using G = Geom<MT, NT, S, D>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int col = lane & 31;
+    const int kh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int g = blockIdx.y;
+    const int ox0 = tx * kTileW;
+    const int oy0 = ty * G::kTileH;
+    const int plane = H * W;
+
+    // ---- per-lane DMA source offsets, computed once --------------------------------------------------
+    unsigned in_off[G::kInSlots];
+#pragma unroll
+    for (int j = 0; j < G::kInSlots; ++j) {
+        const int i = j * kThreads + tid;
+        const int c = i / G::kCH;
+        const int rem = i % G::kCH;
+        const int r = rem / G::kInW;
+        const int xx = rem % G::kInW;
+        int iy;
+        if constexpr (G::kRowSep) {
+            iy = oy0 + (r % G::kTileH) - D + (r / G::kTileH) * D;
+        } else {
+            iy = oy0 * S - D + r;
+        }
+        const int ix = ox0 * S - D + xx;
+        const bool ok = (i < G::kInElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+        in_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+    }
+    unsigned w_off[G::kWSlots];
+#pragma unroll
+    for (int j = 0; j < G::kWSlots; ++j) {
+        const int p = j * kThreads + tid;                       // 16-byte piece index inside the chunk image
+        const int row = p / (G::kCoutT / 4);                    // (c*9 + tap)
+        const int q = p % (G::kCoutT / 4);
+        w_off[j] = (p < G::kWPieces) ? (unsigned)(row * CoutP + q * 4) * 4u : kOOB;
+    }
+
+    // ---- accumulators start at the bias: D row (cout) of register j is (j&3) + 8*(j>>2) + 4*kh --------
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            const float bv = bias[min(co, Cout - 1)];          // rows >= Cout are never stored
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt][j] = bv;
+        }
+    }
+
+    const float *xb = x + (int64_t)b * bsx;
+    const int nchunks = (Cin + kCK - 1) / kCK;
+    const int64_t wchunk = (int64_t)kCK * 9 * CoutP;            // floats per packed chunk
+    const float *wg = wp + g * G::kCoutT;                       // this workgroup's cout columns
+    const unsigned wbytes = (unsigned)(wchunk - g * G::kCoutT) * 4u;
+
+    issue_chunk<G>(xb, wg, 0, Cin, plane, wchunk, wbytes, wave, smem, in_off, w_off);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        float *cur = smem + (chunk & 1) * G::kBufFloats;
+        // This wave's DMA of `chunk` has landed (explicit wait: hipcc does not reliably keep its own
+        // vmcnt(0) in front of the in-loop barrier for LDS-DMA), then the barrier makes every wave's
+        // part visible and guarantees the other buffer is no longer being read.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (chunk + 1 < nchunks)
+            issue_chunk<G>(xb, wg, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
+                           in_off, w_off);
+
+        const float *rd_in = cur + kh * G::kCH + (wave * NT) * S * G::kInW + col * S;
+        const float *rd_w = cur + G::kInRegion + kh * 9 * G::kCoutT + col;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int cp = 0; cp < kCK / 2; ++cp) {
+                float a[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = rd_w[(cp * 2 * 9 + tap) * G::kCoutT + mt * 32];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bv[nt] = rd_in[cp * 2 * G::kCH + ky * G::kKyStride + kx * D + nt * S * G::kInW];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: LeakyReLU / residual, 128-byte row-segment stores ----------------------------------
+    const int ox = ox0 + col;
+    const int64_t oplane = (int64_t)Ho * Wo;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + wave * NT + nt;
+        if (oy >= Ho || ox >= Wo) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+                if (co >= Cout) continue;
+                float v = acc[mt][nt][j];
+                if (do_leaky) v = leaky(v, slope);
+                const int64_t off = (int64_t)co * oplane + (int64_t)oy * Wo + ox;
+                if (residual) v += residual[(int64_t)b * bsr + off];
+                y[(int64_t)b * bsy + off] = v;
+            }
+        }
+    }
+}
+
+}  // namespace (anonymous)
+
+struct ConvArgs {
+    const float *x, *wp, *bias, *residual;
+    float *y;
+    int B, Cin, H, W, Cout, CoutP, Ho, Wo;
+    int64_t bsx, bsy, bsr;
+    float slope;
+    int do_leaky;
+    hipStream_t stream;
+};
+
+namespace {
+
+template <int MT, int NT, int S, int D>
+int launch(const ConvArgs &a) {
+    using G = Geom<MT, NT, S, D>;
+    const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+    const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
+    const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
+    const int groups = (a.CoutP / 32 + MT - 1) / MT;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: grid too large");
+    auto kern = conv3x3_mfma_kernel<MT, NT, S, D>;
+    static bool attr_set = false;   // one per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kSmemBytes);
+        if (e != hipSuccess)
+            PWC_FAIL((int)e, "pwc_conv2d_fwd: hipFuncSetAttribute(%d B LDS): %s", G::kSmemBytes, hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
+                       a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
+                       tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky);
+    return pwc::check_launch("conv3x3_mfma_kernel");
+}
+
+// (MT, NT) choice: fewest "rounds x per-block work" on 256 CUs, one workgroup per CU.
+//   work per block per chunk ~ MT*NT MFMA tile-steps + ~0.35 of fixed cost (barrier, DMA issue, drain)
+struct TileChoice { int mt, nt; };
+inline TileChoice choose_tile(int B, int Ho, int Wo, int CoutP, int max_nt, int max_mt) {
+    const int tiles32 = CoutP / 32;
+    const int tiles_x = (Wo + kTileW - 1) / kTileW;
+    TileChoice best{1, 1};
+    double best_cost = 1e300;
+    for (int mt = 1; mt <= max_mt; ++mt) {
+        if (mt > tiles32) break;
+        const int groups = (tiles32 + mt - 1) / mt;
+        for (int nt = 1; nt <= max_nt; nt *= 2) {
+            if (mt * nt > 16) continue;
+            const int tiles_y = (Ho + 4 * nt - 1) / (4 * nt);
+            const double blocks = (double)B * tiles_x * tiles_y * groups;
+            const double rounds = (double)(int64_t)((blocks + 255) / 256);
+            const double cost = rounds * (mt * nt + 0.35) * (1.0 + 0.02 * groups);   // mild penalty: input re-read per group
+            if (cost < best_cost) { best_cost = cost; best = {mt, nt}; }
+        }
+    }
+    return best;
+}
+
+// one of these per translation unit
+template <int S, int D, int MAXNT, int MAXMT>
+int dispatch(const ConvArgs &a) {
+    const TileChoice t = choose_tile(a.B, a.Ho, a.Wo, a.CoutP, MAXNT, MAXMT);
+#define PWC_TILE(MT_, NT_) if (t.mt == MT_ && t.nt == NT_) return launch<MT_, NT_, S, D>(a);
+    PWC_TILE(1, 1) PWC_TILE(2, 1) PWC_TILE(3, 1)
+    PWC_TILE(1, 2) PWC_TILE(2, 2) PWC_TILE(3, 2)
+    if constexpr (MAXMT >= 4) { PWC_TILE(4, 1) PWC_TILE(4, 2) }
+    if constexpr (MAXNT >= 4) { PWC_TILE(1, 4) PWC_TILE(2, 4) PWC_TILE(3, 4) PWC_TILE(4, 4) }
+#undef PWC_TILE
+    PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: internal tile choice %dx%d", t.mt, t.nt);
+}
+
+}  // namespace (anonymous)
+
+}  // namespace pwc_conv

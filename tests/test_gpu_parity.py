@@ -286,3 +286,43 @@ def test_forward_rejects_bad_inputs(dev):
         net(torch.zeros(1, 3, 64, 64, device=dev))
     with pytest.raises(PwcHipError):
         net(torch.zeros(1, 6, 64, 64))                         # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ BASELINE-size checks
+def test_conv_level2_geometry_repeatable_and_exact(dev):
+    """dc_conv1-like layer (565->128 @112x256) at batch 4: same tile configuration family as the bench;
+    repeated launches must be bit-identical (no DMA/barrier race) and match the CPU."""
+    from opticalflow_amd import ops
+    B, cin, cout, H, W = 4, 565, 128, 112, 256
+    x = seeded_rand((B, cin, H, W), 90, -1, 1)
+    w = seeded_rand((cout, cin, 3, 3), 91, -1, 1) * (2.0 / (cin * 9)) ** 0.5
+    bias = seeded_rand((cout,), 92, -0.5, 0.5)
+    xd, wp, bd = x.to(dev), ops.pack_conv3x3(w.to(dev)), bias.to(dev)
+    outs = [ops.conv3x3(xd, wp, bd, cout) for _ in range(4)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    torch.set_num_threads(8)
+    ref = F.leaky_relu(F.conv2d(x[:1], w, bias, padding=1), 0.1)
+    assert (outs[0][:1].cpu() - ref).abs().max().item() < 3e-6 * (cin * 9) ** 0.5
+
+
+def test_forward_full_size_batch16(dev):
+    """1024x448, batch 16 (the bench workload): items 0 and 15 against the CPU oracle, and a batch made of
+    16 copies of one pair must give 16 identical flows (tile/race independence), twice in a row."""
+    net, g = _golden_net(dev)
+    x = seeded_rand((16, 6, 448, 1024), 1234)
+    f = net(x.to(dev)).cpu()
+    from opticalflow_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict(net.manifest(), seed=int(g["wseed"]), gain=float(g["gain"]), bias_std=float(g["bias_std"]))
+    torch.set_num_threads(8)
+    for i in (0, 15):
+        with torch.no_grad():
+            ref = O.pwc_forward(sd, x[i:i + 1])
+        e = O.epe(f[i:i + 1], ref)
+        print("full-size item %d: mean|flow2| %.3f EPE vs CPU oracle %.3e" % (i, ref.abs().mean().item(), e))
+        assert e < 1e-3
+    same = x[:1].expand(16, -1, -1, -1).contiguous().to(dev)
+    for _ in range(2):
+        fs = net(same)
+        assert all(torch.equal(fs[0], fs[i]) for i in range(1, 16))
+        assert torch.equal(fs[0].cpu(), f[0])
