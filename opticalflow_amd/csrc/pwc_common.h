@@ -33,6 +33,40 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? 
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- hand-issued LDS-DMA (buffer_load ... lds) ----------------------------------------------------------
+// hipcc treats a builtin LDS-DMA as an LDS store that may alias every later ds_read and drains it with
+// s_waitcnt vmcnt(0) before the first read, which serialises a multi-chunk ring.  Issued from inline asm the
+// DMA is invisible to that bookkeeping; completion is then tracked ONLY by the caller's counted
+// `s_waitcnt vmcnt(N)` + barrier (vmcnt retires in issue order).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor {base, num_records bytes}: built from readfirstlane'd words (wave-uniform SGPRs)
+__device__ __forceinline__ v4i32 make_rsrc(const void *base, int num_bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    v4i32 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xffff;     // stride 0, no swizzle
+    r.z = __builtin_amdgcn_readfirstlane(num_bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+// 64 lanes x 16 B -> LDS[lds_base + lane*16 ..]; lanes whose voffset fails the range check deliver zeros.
+// s_nop 4: SGPR operands may come straight from v_readfirstlane (VALU->VMEM SGPR hazard, not padded inside asm);
+// s_nop 0: M0 write -> LDS-DMA.
+__device__ __forceinline__ void dma_b128(v4i32 rsrc, unsigned lds_base, unsigned voffset) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void dma_b32(v4i32 rsrc, unsigned lds_base, unsigned voffset) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rsrc) : "memory");
+}
+
 }  // namespace pwc
 
 #define PWC_FAIL(code, ...)            \

@@ -193,6 +193,198 @@ corr81_kernel(const T *__restrict__ in1, const T *__restrict__ in2, T *__restric
     }
 }
 
+// ---- fp32 fast path v2 -------------------------------------------------------------------------------------
+// Same tile / lane roles as corr81_kernel (wave = dy, lane = 4 pixels x 9 dx), restructured around what the
+// profile showed on MI355X (profiles/r01_corr_ablation.md): the kernel is VALU-bound, not HBM-bound, unless
+// the fma are packed, and load / compute / store phases of a one-tile workgroup do not overlap.
+//   * PERSISTENT workgroups (2 per CU) walk a strided list of tiles; the LDS image is a 4-deep RING of
+//     4-channel chunks filled by buffer_load_dwordx4 ... lds (LDS-DMA) that runs ahead ACROSS tile
+//     boundaries: up to three chunks stream from HBM while one is consumed, and the 16-byte output stores
+//     of tile t drain while tile t+1's chunks are already being multiplied.
+//   * v_pk_fma_f32 without repacking: for pixel p the accumulators are paired over dx so that the in2
+//     operand pair (w[p+dx], w[p+dx+1]) starts at an EVEN window index (= an aligned VGPR pair straight
+//     out of ds_read_b128) and in1[p] is broadcast: 4 packed + 1 scalar fma per pixel instead of 9.
+//   * zero padding, ragged edges and the ragged last channel chunk come from the buffer range check; every
+//     wave issues exactly kDmaSlots DMA instructions per chunk (15 real ones dealt round-robin to the 9
+//     waves + 3 all-out-of-range dummies into a spare LDS strip) so "chunk s landed" is a counted vmcnt.
+// Needs W % 4 == 0 and 16-byte aligned operands (the launcher falls back to corr81_kernel otherwise).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kCKd = 4;                                   // channels per chunk
+constexpr int kRing = 4;                                  // LDS buffers
+constexpr int kS2Floats = kCKd * kS2Rows * kPitch;        // 2560: in2 halo tile [c][16][40]
+constexpr int kS1Floats = kCKd * kTH * kPitch;            // 1280: in1 tile      [c][8][40] (cols 32..39 unused)
+constexpr int kS2Instr = kS2Floats / 4 / 64;              // 10 wave-instructions of 64 x 16 B
+constexpr int kS1Instr = kS1Floats / 4 / 64;              // 5
+constexpr int kDmaInstr = kS2Instr + kS1Instr;            // 15 real
+constexpr int kDmaSlots = (kDmaInstr + kND - 1) / kND;    // 2 per wave -> 18 issued, 3 dummies
+constexpr int kBufFloats = kDmaSlots * kND * 256;         // 4608 floats = 18 KiB per buffer (incl. dummy strip)
+constexpr unsigned kOOBv = 0x80000000u;
+constexpr int kPersistentPerCU = 2;
+
+struct TileXY { int b, x0, y0; };
+
+__device__ __forceinline__ TileXY tile_of(int t, int nblk, int tiles_x, int tiles_y) {
+    // tiles are dealt so that each XCD (blocks i, i+8, ... share one) owns a contiguous run: the +-4 halo
+    // re-read by neighbouring tiles then hits in that XCD's L2 (speed only, any mapping is correct)
+    if ((nblk & 7) == 0) t = (t & 7) * (nblk >> 3) + (t >> 3);
+    TileXY r;
+    r.x0 = (t % tiles_x) * kTW;
+    t /= tiles_x;
+    r.y0 = (t % tiles_y) * kTH;
+    r.b = t / tiles_y;
+    return r;
+}
+
+__device__ __forceinline__ void corr_offsets(unsigned (&off)[kDmaSlots], int wave, int lane, const TileXY &t,
+                                             int H, int W, int plane) {
+#pragma unroll
+    for (int j = 0; j < kDmaSlots; ++j) {
+        const int k = wave + kND * j;
+        int c, row, q, iy, ix;
+        bool ok;
+        if (k < kS2Instr) {
+            const int p = k * 64 + lane;
+            c = p / (kS2Rows * 10); row = (p / 10) % kS2Rows; q = p % 10;
+            iy = t.y0 + row - kD; ix = t.x0 + 4 * q - kD;
+            ok = true;
+        } else {
+            const int p = (k - kS2Instr) * 64 + lane;
+            c = p / (kTH * 10); row = (p / 10) % kTH; q = p % 10;
+            iy = t.y0 + row; ix = t.x0 + 4 * q;
+            ok = (k < kDmaInstr) && (q < kTG);
+        }
+        ok = ok && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);     // W % 4 == 0: a piece is all-in or all-out
+        off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOBv;
+    }
+}
+
+__device__ __forceinline__ void corr_issue(const float *p1, const float *p2, int c0, int C, int plane, int wave,
+                                           float *buf, const unsigned (&off)[kDmaSlots]) {
+    const int nbytes = min(kCKd, C - c0) * plane * 4;
+    const pwc::v4i32 r2 = pwc::make_rsrc(p2 + (int64_t)c0 * plane, nbytes);
+    const pwc::v4i32 r1 = pwc::make_rsrc(p1 + (int64_t)c0 * plane, nbytes);
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
+#pragma unroll
+    for (int j = 0; j < kDmaSlots; ++j) {
+        const int k = wave + kND * j;                       // wave-uniform instruction index, 0..17
+        if (k < kS2Instr) {
+            pwc::dma_b128(r2, base + k * 1024, off[j]);
+        } else {                                            // in1 pieces, or an all-OOB dummy (k >= kDmaInstr)
+            pwc::dma_b128(r1, base + k * 1024, off[j]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads, 5)
+corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, float *__restrict__ out,
+                  int C, int H, int W, int tiles_x, int tiles_y, int nblk,
+                  int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky) {
+    __shared__ __attribute__((aligned(16))) float smem[kRing * kBufFloats];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // dyi = dy + 4
+    const int lane = tid & 63;
+    int r, g;
+    lane_to_rg(lane, r, g);
+    const int plane = H * W;
+    const int nchunks = (C + kCKd - 1) / kCKd;
+    const int stride = gridDim.x;
+    const int my_tiles = (nblk - (int)blockIdx.x + stride - 1) / stride;      // tiles blockIdx.x, +stride, ...
+    const int nsteps = my_tiles * nchunks;
+
+    // ---- issue side (runs up to kRing-1 steps ahead of the compute side) -----------------------------
+    int is_tile = blockIdx.x, is_chunk = 0, is_step = 0;
+    unsigned off[kDmaSlots];
+    const float *ip1 = nullptr, *ip2 = nullptr;
+    auto issue_next = [&]() {
+        if (is_step >= nsteps) return;
+        if (is_chunk == 0) {
+            const TileXY t = tile_of(is_tile, nblk, tiles_x, tiles_y);
+            corr_offsets(off, wave, lane, t, H, W, plane);
+            ip1 = in1 + (int64_t)t.b * bs1;
+            ip2 = in2 + (int64_t)t.b * bs2;
+        }
+        corr_issue(ip1, ip2, is_chunk * kCKd, C, plane, wave, smem + (is_step % kRing) * kBufFloats, off);
+        ++is_step;
+        if (++is_chunk == nchunks) { is_chunk = 0; is_tile += stride; }
+    };
+#pragma unroll
+    for (int k = 0; k < kRing - 1; ++k) issue_next();
+
+    // ---- compute side ----------------------------------------------------------------------------------
+    // pixel p even: pairs dx = (0,1)(2,3)(4,5)(6,7) + single dx 8;  p odd: pairs (1,2)(3,4)(5,6)(7,8) + single dx 0
+    f32x2 acc2[kPX][4];
+    float acc1[kPX];
+#pragma unroll
+    for (int p = 0; p < kPX; ++p) {
+        acc1[p] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc2[p][m] = (f32x2){0.f, 0.f};
+    }
+    int tile = blockIdx.x, chunk = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // steps s+1 .. s+ahead were issued after step s and may stay in flight
+        const int ahead = min(kRing - 2, nsteps - 1 - s);
+        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaSlots) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaSlots) : "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // every wave's part of step s landed; ring slot (s-1)%kRing is free
+        issue_next();                       // step s + kRing - 1
+        const float *cur = smem + (s % kRing) * kBufFloats;
+        const float *s2 = cur + (r + wave) * kPitch + 4 * g;
+        const float *s1 = cur + kS2Floats + r * kPitch + 4 * g;
+#pragma unroll 2
+        for (int c = 0; c < kCKd; ++c) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(s1 + c * kTH * kPitch);
+            const float4 w0 = *reinterpret_cast<const float4 *>(s2 + c * kS2Rows * kPitch);
+            const float4 w1 = *reinterpret_cast<const float4 *>(s2 + c * kS2Rows * kPitch + 4);
+            const float4 w2 = *reinterpret_cast<const float4 *>(s2 + c * kS2Rows * kPitch + 8);
+            const float a[kPX] = {a4.x, a4.y, a4.z, a4.w};
+            const f32x2 wp[6] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}, {w2.x, w2.y}, {w2.z, w2.w}};
+            const float ws[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+            for (int p = 0; p < kPX; ++p) {
+                const f32x2 ap = {a[p], a[p]};
+                const int m0 = (p + 1) / 2;                 // first aligned window pair: index p (p even) / p+1 (p odd)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc2[p][m] = __builtin_elementwise_fma(ap, wp[m0 + m], acc2[p][m]);
+                acc1[p] = fmaf(a[p], (p & 1) ? ws[p] : ws[p + 8], acc1[p]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads done before the slot can be refilled
+        if (++chunk == nchunks) {
+            // ---- tile finished: scale / LeakyReLU / 16-byte stores (they drain while the next tile runs)
+            const TileXY t = tile_of(tile, nblk, tiles_x, tiles_y);
+            const int y = t.y0 + r;
+            const int x = t.x0 + 4 * g;
+            if (y < H && x < W) {
+                float *po = out + (int64_t)t.b * bso + (int64_t)(wave * kND) * plane + (int64_t)y * W + x;
+#pragma unroll
+                for (int dx = 0; dx < kND; ++dx) {
+                    float v[kPX];
+#pragma unroll
+                    for (int p = 0; p < kPX; ++p) {
+                        float q;
+                        if (p & 1) q = (dx == 0) ? acc1[p] : acc2[p][(dx - 1) / 2][(dx - 1) & 1];
+                        else       q = (dx == 8) ? acc1[p] : acc2[p][dx / 2][dx & 1];
+                        q *= scale;
+                        v[p] = do_leaky ? leaky(q, slope) : q;
+                    }
+                    *reinterpret_cast<float4 *>(po + (int64_t)dx * plane) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < kPX; ++p) {
+                acc1[p] = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc2[p][m] = (f32x2){0.f, 0.f};
+            }
+            chunk = 0;
+            tile += stride;
+        }
+    }
+}
+
 // Any (pad, kernel, max_disp, stride1, stride2): one thread per output element.
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -300,6 +492,14 @@ int launch_corr(const void *in1, const void *in2, void *out, int B, int C, int H
         const bool ptr_ok = ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2) |
                               reinterpret_cast<uintptr_t>(out)) & (uintptr_t)(va * elt - 1)) == 0;
         const int vec = (W % 4 == 0) && ptr_ok && (bs1 % 4 == 0) && (bs2 % 4 == 0) && (bso % 4 == 0);
+        if constexpr (sizeof(T) == 4) {
+            if (vec && (int64_t)H * W * kCKd * 4 < 0x7fffffffLL) {
+                const int grid = (int)((nblk < kPersistentPerCU * 256) ? nblk : kPersistentPerCU * 256);
+                hipLaunchKernelGGL(corr81_dma_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st,
+                                   a, b, o, C, H, W, tiles_x, tiles_y, (int)nblk, bs1, bs2, bso, scale, slope, do_leaky);
+                return pwc::check_launch("corr81_dma_kernel");
+            }
+        }
         hipLaunchKernelGGL((corr81_kernel<T, 8>), dim3((unsigned)nblk), dim3(kThreads), 0, st,
                            a, b, o, C, H, W, tiles_x, tiles_y, bs1, bs2, bso, scale, slope, do_leaky, vec);
         return pwc::check_launch("corr81_kernel");

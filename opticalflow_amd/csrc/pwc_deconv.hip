@@ -1,0 +1,118 @@
+// ConvTranspose2d(kernel 4, stride 2, padding 1) with 2 output channels: deconv{6..3} (2 -> 2) and
+// upfeat{6..3} (529..597 -> 2) of the reference (models/PWCNet.py:35-36, used :208-209,222-223,236-237,252-253).
+//
+//   y[co, 2*iy + py, 2*ix + px] = bias[co] + sum_ci sum_{2x2 taps} x[ci, iy + dy, ix + dx] * w[ci, co, ky, kx]
+//   with oy = 2*iy' - 1 + ky:   py = 0 -> (iy-1, ky=3), (iy, ky=1);   py = 1 -> (iy, ky=2), (iy+1, ky=0)   (same in x)
+//
+// Input-anchored: a lane owns one input pixel and produces the 2x2 output quad it anchors from its 3x3
+// neighbourhood, so every input value is loaded once per lane and reused by 4 outputs x 2 couts.  The
+// reduction over Cin is split across the 8 waves of the workgroup (wave w takes channels w, w+8, ...), which
+// all cover the SAME 8x8 pixel tile; partial sums meet in LDS.  That keeps ~600-channel upfeat layers from
+// being one long serial loop per thread (the first version ran 300 us per call regardless of level).
+// Weights are wave-uniform (scalar loads).  fp32 only.
+#include "pwc_common.h"
+
+namespace {
+
+constexpr int kDWaves = 8;
+constexpr int kDThreads = 64 * kDWaves;
+constexpr int kDTile = 8;            // 8 x 8 input pixels per workgroup
+
+template <int CO>
+__global__ void __launch_bounds__(kDThreads)
+deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                   float *__restrict__ y, int Cin, int H, int W, int tiles_x, int tiles_y,
+                   int64_t bsx, int64_t bsy) {
+    __shared__ float red[kDWaves][CO * 4][64];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int iy = ty * kDTile + (lane >> 3);
+    const int ix = tx * kDTile + (lane & 7);
+    const int64_t plane = (int64_t)H * W;
+    const float *xb = x + (int64_t)b * bsx;
+
+    // clamped neighbourhood offsets + validity (out-of-image taps contribute 0)
+    int off[3][3];
+    float msk[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int yy = iy - 1 + a, xx = ix - 1 + c;
+            const bool ok = (yy >= 0) && (yy < H) && (xx >= 0) && (xx < W);
+            off[a][c] = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+            msk[a][c] = ok ? 1.f : 0.f;
+        }
+
+    float acc[CO][2][2];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[co][0][0] = acc[co][0][1] = acc[co][1][0] = acc[co][1][1] = 0.f;
+
+    for (int ci = wave; ci < Cin; ci += kDWaves) {
+        const float *xp = xb + (int64_t)ci * plane;
+        float v[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[a][c] = xp[off[a][c]] * msk[a][c];
+        const float *wc = w + (int64_t)ci * CO * 16;          // wave-uniform
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const float *k = wc + co * 16;                    // k[ky*4 + kx]
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int kya = py ? 2 : 3, kyb = py ? 0 : 1;       // rows v[py], v[py+1]
+                    const int kxa = px ? 2 : 3, kxb = px ? 0 : 1;       // cols v[.][px], v[.][px+1]
+                    float s = acc[co][py][px];
+                    s = fmaf(v[py][px], k[kya * 4 + kxa], s);
+                    s = fmaf(v[py][px + 1], k[kya * 4 + kxb], s);
+                    s = fmaf(v[py + 1][px], k[kyb * 4 + kxa], s);
+                    s = fmaf(v[py + 1][px + 1], k[kyb * 4 + kxb], s);
+                    acc[co][py][px] = s;
+                }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave][co * 4 + q][lane] = acc[co][q >> 1][q & 1];
+    __syncthreads();
+    // wave w finishes output value (co, q) = w of every pixel: fixed summation order -> deterministic
+    if (wave < CO * 4) {
+        float s = bias[wave >> 2];
+#pragma unroll
+        for (int k = 0; k < kDWaves; ++k) s += red[k][wave][lane];
+        if (iy < H && ix < W) {
+            const int co = wave >> 2, py = (wave >> 1) & 1, px = wave & 1;
+            y[(int64_t)b * bsy + (int64_t)co * 4 * plane + (int64_t)(2 * iy + py) * (2 * W) + 2 * ix + px] = s;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bias, void *y,
+                                   int B, int Cin, int H, int W, int Cout, int dtype,
+                                   int64_t x_bstride, int64_t y_bstride, void *stream) {
+    if (!x || !w || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_deconv4x4s2_fwd: null pointer");
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_deconv4x4s2_fwd: bad shape");
+    if (Cout != 2) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_deconv4x4s2_fwd: Cout=%d (PWC-Net only has 2-channel deconvs)", Cout);
+    if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_deconv4x4s2_fwd: dtype %d", dtype);
+    const int tiles_x = (W + kDTile - 1) / kDTile;
+    const int tiles_y = (H + kDTile - 1) / kDTile;
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_deconv4x4s2_fwd: grid too large");
+    hipLaunchKernelGGL((deconv4x4s2_kernel<2>), dim3((unsigned)nblk), dim3(kDThreads), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(x), static_cast<const float *>(w), static_cast<const float *>(bias),
+                       static_cast<float *>(y), Cin, H, W, tiles_x, tiles_y, x_bstride, y_bstride);
+    return pwc::check_launch("deconv4x4s2_kernel");
+}

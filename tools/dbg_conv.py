@@ -1,5 +1,5 @@
 import sys, torch, torch.nn.functional as F
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, 'tests')
 from conftest import seeded_rand
 from opticalflow_amd import ops

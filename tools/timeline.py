@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace CSV: per-launch timeline of ONE forward of bench.py.
+
+usage: tools/timeline.py <kernel_trace.csv> [--full]
+A forward starts at the two back-to-back stride-2 launches of conv1a on the two images.
+"""
+import csv
+import re
+import sys
+
+
+def short(n):
+    m = re.search(r"conv3x3_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", n)
+    if m:
+        return "mfma<MT%s,NT%s,S%s,D%s>" % m.groups()
+    for k in ("conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "warp_kernel", "copyBuffer", "elementwise", "pack3x3"):
+        if k in n:
+            return k
+    return n[:30]
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    names = [short(r["Kernel_Name"]) for r in rows]
+    starts = [i for i in range(len(rows) - 1)
+              if names[i].endswith("S2,D1>") and names[i + 1] == names[i]
+              and rows[i]["Grid_Size_X"] == rows[i + 1]["Grid_Size_X"] and int(rows[i]["Grid_Size_X"]) > 256 * 1000]
+    if len(starts) < 3:
+        print("no forward found")
+        return
+    s, e = starts[-2], starts[-1]
+    t0 = int(rows[s]["Start_Timestamp"])
+    agg = {}
+    tot = 0.0
+    for r, n in zip(rows[s:e], names[s:e]):
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        tot += d
+        a = agg.setdefault(n, [0, 0.0])
+        a[0] += 1
+        a[1] += d
+        if "--full" in sys.argv:
+            print("%8.1f us  +%8.1f  %-22s grid=(%d,%s)" % (d, (int(r["Start_Timestamp"]) - t0) / 1e3, n,
+                                                          int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), r["Grid_Size_Y"]))
+    span = (int(rows[e]["Start_Timestamp"]) - t0) / 1e3
+    print("one forward: %d launches, kernel time %.1f us, span %.1f us" % (e - s, tot, span))
+    for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("  %-24s x%3d  %9.1f us  %5.1f %%" % (n, c, d, 100 * d / tot))
+
+
+if __name__ == "__main__":
+    main()
