@@ -1,0 +1,164 @@
+"""CPU-only tests: host logic of the drop-in interface and the C-ABI library's loadability.
+No compute call is made (there is no GPU here); kernels are exercised by tests/test_gpu_parity.py."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden
+from oracle import pwc_oracle as O
+
+
+# ------------------------------------------------------------------ C ABI
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "pwc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pwc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from opticalflow_amd import _lib
+    names = _declared_symbols()
+    assert "pwc_corr_fwd" in names and "pwc_warp_fwd" in names and "pwc_conv2d_fwd" in names
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and include/pwc_hip.h disagree"
+    assert os.path.exists(_lib.LIB_PATH), "libpwc_hip.so not built (run __graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    assert _lib.load().pwc_abi_version() == _lib.ABI_VERSION
+
+
+def test_abi_argument_errors_without_gpu():
+    """Argument validation happens before any launch, so it can be checked without a device."""
+    from opticalflow_amd import _lib
+    lib = _lib.load()
+    assert lib.pwc_corr_fwd(None, None, None, 1, 1, 1, 1, 4, 1, 4, 1, 1, 1.0, 0, 0, 0.0, 1, 1, 1, None) == -1
+    assert b"null pointer" in lib.pwc_last_error()
+    assert lib.pwc_conv3x3_packed_bytes(565, 128, 0) == 71 * 8 * 9 * 128 * 4
+    assert lib.pwc_conv3x3_packed_bytes(32, 2, 0) == (4 * 8 * 9 * 32 + 2 * 32 * 9) * 4   # MFMA image + raw tail
+    assert lib.pwc_conv3x3_packed_bytes(0, 2, 0) == -1
+    assert lib.pwc_conv3x3_packed_bytes(8, 8, 1) == -1          # f16 weights not supported
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from opticalflow_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.PwcHipError):
+        _lib.load()
+
+
+# ------------------------------------------------------------------ model surface
+def test_state_dict_matches_reference_manifest():
+    from opticalflow_amd import PWCDCNet
+    g = load_golden("g5_manifest.npz")
+    torch.manual_seed(0)
+    net = PWCDCNet()
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    assert net.manifest() == O.state_dict_manifest()
+    # same construction order + same init recipe as the reference -> same weights for the same seed
+    sums = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    assert np.allclose(sums, g["seed0_abs_sums"], rtol=1e-12, atol=0)
+
+
+def test_checkpoint_layouts(tmp_path):
+    from opticalflow_amd import PWCDCNet, pwc_dc_net
+    from opticalflow_amd.weights import load_checkpoint, synthetic_state_dict
+    sd = synthetic_state_dict(PWCDCNet().manifest(), seed=3, gain=0.5, bias_std=0.1)
+    layouts = {"bare": sd, "state_dict": {"state_dict": sd, "epoch": 3},
+               "model": {"model": {("module." + k): v for k, v in sd.items()}, "optimizer": {}}}
+    for name, obj in layouts.items():
+        path = str(tmp_path / (name + ".pth.tar"))
+        torch.save(obj, path)
+        got = load_checkpoint(path)
+        assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd), name
+        net = pwc_dc_net(path)
+        assert torch.equal(net.state_dict()["dc_conv7.bias"], sd["dc_conv7.bias"])
+    bad = dict(sd)
+    bad.pop("deconv2.weight")           # defined but unused by forward; still required by strict loading
+    with pytest.raises(RuntimeError):
+        PWCDCNet().load_state_dict(bad)
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    from opticalflow_amd import Correlation, PWCDCNet, PwcHipError
+    net = PWCDCNet().eval()
+    with pytest.raises(PwcHipError):
+        net(torch.zeros(1, 6, 64, 64))
+    with pytest.raises(PwcHipError):
+        net.warp(torch.zeros(1, 4, 8, 8), torch.zeros(1, 2, 8, 8))
+    with pytest.raises(PwcHipError):
+        Correlation(4, 1, 4, 1, 1)(torch.zeros(1, 4, 8, 8), torch.zeros(1, 4, 8, 8))
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 5, 64, 64))
+
+
+def test_plan_constants_match_reference_channel_counts():
+    from opticalflow_amd import engine
+    # od per level (PWCNet.py:77,87,97,107,117) and dense growth (PWCNet.py:75)
+    assert [engine.level_in_channels(l) for l in (6, 5, 4, 3, 2)] == [81, 213, 181, 149, 117]
+    assert engine.DENSE_TOTAL == 448 and list(engine.DENSE_OFF) == [320, 192, 96, 32, 0]
+    for l in (6, 5, 4, 3, 2):
+        od = engine.level_in_channels(l)
+        lo = engine.DENSE_TOTAL
+        for i, (co, off) in enumerate(zip(engine.DENSE_OUT, engine.DENSE_OFF)):
+            cin = engine.DENSE_TOTAL + od - lo          # channels a suffix starting at `lo` holds
+            assert cin == od + sum(engine.DENSE_OUT[:i])
+            assert off + co == lo                         # the new block sits right in front of its input
+            lo = off
+    with pytest.raises(ValueError):
+        engine.PwcPlan({}, 1, 100, 128, torch.device("cpu"))
+
+
+def test_correlation_shape_contract():
+    from opticalflow_amd import ops
+    assert ops.corr_output_shape(32, 112, 256, 4, 1, 4, 1, 1) == (81, 112, 256)
+    assert ops.corr_output_shape(6, 10, 12, 4, 1, 4, 1, 2) == (25, 10, 12)
+    assert ops.corr_output_shape(4, 15, 17, 3, 3, 6, 2, 2) == O.corr_output_shape(4, 15, 17, 3, 3, 6, 2, 2)
+    assert ops.corr_output_shape(16, 64, 64, 20, 3, 20, 1, 2) == (441, 62, 62)   # FlowNetC-style config
+
+
+def test_traceable_export_expression_matches_oracle():
+    """The opt-in exporter expression (reference's USE_ONNX_CORRELATION switch) states the same cost volume."""
+    import opticalflow_amd.correlation as C
+    a = torch.randn(1, 5, 9, 11, generator=torch.Generator().manual_seed(1))
+    b = torch.randn(1, 5, 9, 11, generator=torch.Generator().manual_seed(2))
+    got = C.correlation_traceable(a, b, 4, 1, 4, 1, 1, 1)
+    assert torch.allclose(got, O.correlation(a, b, 4, 1, 4, 1, 1, 1), atol=1e-5)
+    assert C.USE_ONNX_CORRELATION is False
+
+
+# ------------------------------------------------------------------ .flo
+def test_flo_roundtrip_and_known_bytes(tmp_path):
+    from opticalflow_amd import read_flo, write_flo
+    g = load_golden("g4_flo.npz")
+    path = str(tmp_path / "a.flo")
+    write_flo(path, g["uv"])
+    assert open(path, "rb").read() == g["blob"].tobytes()
+    assert np.array_equal(read_flo(path), g["uv"])
+    write_flo(path, torch.from_numpy(g["uv"]))
+    assert np.array_equal(read_flo(path), g["uv"])
+    open(path, "wb").write(b"XXXX" + g["blob"].tobytes()[4:])
+    with pytest.raises(ValueError):
+        read_flo(path)
+    open(path, "wb").write(g["blob"].tobytes()[:-8])
+    with pytest.raises(ValueError):
+        read_flo(path)
+    with pytest.raises(ValueError):
+        write_flo(path, np.zeros((3, 5, 3), np.float32))
+
+
+def test_drop_in_import_paths():
+    import models
+    from models.correlation_package.correlation import Correlation
+    import correlation_cuda
+    assert callable(models.pwc_dc_net) and callable(correlation_cuda.forward) and callable(correlation_cuda.backward)
+    m = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
+    assert (m.pad_size, m.kernel_size, m.max_displacement, m.stride1, m.stride2, m.corr_multiply) == (4, 1, 4, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        models.pwc_dc_net_old()
