@@ -104,6 +104,16 @@ int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bias, void *y,
                         int64_t x_bstride, int64_t y_bstride,
                         void *stream);
 
+/* predict_flowL (Conv2d Cin->2, 3x3) and upfeatL (ConvTranspose2d Cin->2, k4 s2 p1) in ONE pass over x:
+ * both read the same 3x3 window of the same [B,Cin,H,W] arena (PWCNet.py:207+209, 221+223, 235+237, 251+253).
+ * head_wp = pwc_conv3x3_pack of the [2,Cin,3,3] head filters; up_w = [Cin,2,4,4] (nn layout).
+ * flow:[B,2,H,W], up_out:[B,2,2H,2W].  Returns PWC_EUNSUPPORTED (nothing launched) when the geometry is
+ * outside the streaming kernel (W % 4 != 0, W < 128, unaligned): call the two separate entry points then. */
+int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const void *head_bias, void *flow,
+                        const void *up_w, const void *up_bias, void *up_out,
+                        int B, int Cin, int H, int W, int dtype,
+                        int64_t x_bstride, int64_t flow_bstride, int64_t up_bstride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,8 @@ SIGNATURES = {
                                c_int64, c_int64, c_int64, c_void_p]),
     "pwc_deconv4x4s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "pwc_head_upfeat_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
 }
 
 _lib = None

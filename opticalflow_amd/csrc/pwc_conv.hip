@@ -16,18 +16,26 @@ int run_s2d1(const ConvArgs &a);
 int run_head(const float *x, const float *w_raw, const float *bias, const float *residual, float *y,
              int B, int Cin, int H, int W, int Cout, int64_t bsx, int64_t bsy, int64_t bsr,
              float slope, int do_leaky, hipStream_t st);
+bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx);
+int stream3x3_head(const float *x, const float *w, const float *bias, const float *residual, float *y,
+                   int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, int64_t bsr,
+                   float slope, int do_leaky, hipStream_t st);
+int stream3x3_head_upfeat(const float *x, int B, int Cin, int H, int W, int64_t bsx,
+                          const float *hw, const float *hbias, float *hy, int64_t bshy,
+                          const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st);
 }  // namespace pwc_conv
 
 namespace {
 
-using pwc_conv::kCK;
+constexpr int kCK = pwc_conv::kPackCK;     // packing granularity (kernels consume 4- or 8-channel chunks of it)
 
 inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
 inline int conv_chunks(int Cin) { return (Cin + kCK - 1) / kCK; }
 // floats of the MFMA image [chunk][c][tap][CoutP]; 2-channel heads append the raw [Cout][Cin][9] filters
 // (read by the VALU head kernel) after it
 inline int64_t mfma_image_floats(int Cin, int Cout) { return (int64_t)conv_chunks(Cin) * kCK * 9 * cout_padded(Cout); }
-inline int64_t raw_tail_floats(int Cin, int Cout) { return Cout == 2 ? ((int64_t)Cout * Cin * 9 + 3) / 4 * 4 : 0; }
+//   tail layout: [ci][20] = {co0: 9 taps, 0, co1: 9 taps, 0}: 80-byte rows so a 4-channel chunk is 20 aligned 16-byte pieces
+inline int64_t raw_tail_floats(int Cin, int Cout) { return Cout == 2 ? (int64_t)Cin * 20 : 0; }
 
 // wp[chunk][c][tap][co] <- w[co][chunk*8 + c][tap], zero padded to CoutP columns / 8-channel chunks
 __global__ void __launch_bounds__(256)
@@ -37,7 +45,9 @@ pack3x3_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cin, int
     if (i >= total) return;
     if (i >= image) {                          // raw tail
         const int64_t k = i - image;
-        wp[i] = (k < (int64_t)Cout * Cin * 9) ? w[k] : 0.f;
+        const int ci = (int)(k / 20), r = (int)(k % 20);
+        const int co = r / 10, tap = r % 10;
+        wp[i] = (tap < 9) ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.f;
         return;
     }
     const int co = (int)(i % CoutP);
@@ -83,7 +93,7 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
     if ((flags & PWC_CONV_RESIDUAL) && !residual) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: residual flag without pointer");
     const int64_t plane = (int64_t)H * W;
     if (x_bstride < Cin * plane) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: x batch stride < Cin*H*W");
-    if (plane * pwc_conv::kCK * 4 >= 0x7fffffffLL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_fwd: image plane too large for 32-bit DMA offsets");
+    if (plane * kCK * 4 >= 0x7fffffffLL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_fwd: image plane too large for 32-bit DMA offsets");
     pwc_conv::ConvArgs a;
     a.x = static_cast<const float *>(x);
     a.wp = static_cast<const float *>(wp);
@@ -98,9 +108,17 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
     a.do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
     a.stream = static_cast<hipStream_t>(stream);
     if (Cout == 2 && stride == 1 && dilation == 1) {
-        const int rc = pwc_conv::run_head(a.x, a.wp + mfma_image_floats(Cin, Cout), a.bias, a.residual, a.y, B, Cin, H, W,
-                                          Cout, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky, a.stream);
-        if (rc != PWC_EUNSUPPORTED) return rc;         // else: shape/alignment outside the head kernel's fast path
+        // 2-channel heads: stream the arena through the LDS ring when the image is wide enough, split Cin over
+        // waves when the level is tiny; in between the MFMA kernel (MT=1) is still the fastest
+        const float *w_raw = a.wp + mfma_image_floats(Cin, Cout);
+        int rc = PWC_EUNSUPPORTED;
+        if (pwc_conv::stream3x3_ok(B, Cin, H, W, a.x, a.bsx))
+            rc = pwc_conv::stream3x3_head(a.x, w_raw, a.bias, a.residual, a.y, B, Cin, H, W, a.bsx, a.bsy, a.bsr,
+                                          a.slope, a.do_leaky, a.stream);
+        else if ((int64_t)B * H * W <= 4096)
+            rc = pwc_conv::run_head(a.x, w_raw, a.bias, a.residual, a.y, B, Cin, H, W, Cout, a.bsx, a.bsy, a.bsr,
+                                    a.slope, a.do_leaky, a.stream);
+        if (rc != PWC_EUNSUPPORTED) return rc;
     }
     if (stride == 1) {
         switch (dilation) {
@@ -115,4 +133,30 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
     }
     PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_fwd: stride %d dilation %d has no kernel (stride 1: dilation 1,2,4,8,16; stride 2: dilation 1)",
              stride, dilation);
+}
+
+// predict_flowL + upfeatL in ONE pass over the level's arena (they read the same 3x3 window of the same
+// [B,Cin,H,W] tensor; reference models/PWCNet.py:207+209, 221+223, 235+237, 251+253).  Returns
+// PWC_EUNSUPPORTED when the geometry is outside the streaming kernel's range: the caller then issues
+// pwc_conv2d_fwd and pwc_deconv4x4s2_fwd separately.
+extern "C" int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const void *head_bias, void *flow,
+                                   const void *up_w, const void *up_bias, void *up_out,
+                                   int B, int Cin, int H, int W, int dtype,
+                                   int64_t x_bstride, int64_t flow_bstride, int64_t up_bstride, void *stream) {
+    if (!x || !head_wp || !head_bias || !flow || !up_w || !up_bias || !up_out) PWC_FAIL(PWC_EINVAL, "pwc_head_upfeat_fwd: null pointer");
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_head_upfeat_fwd: bad shape");
+    if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_head_upfeat_fwd: dtype %d", dtype);
+    if (x_bstride < (int64_t)Cin * H * W) PWC_FAIL(PWC_EINVAL, "pwc_head_upfeat_fwd: x batch stride < Cin*H*W");
+    const float *xf = static_cast<const float *>(x);
+    if (!pwc_conv::stream3x3_ok(B, Cin, H, W, xf, x_bstride)) {
+        pwc::set_error("pwc_head_upfeat_fwd: geometry %dx%dx%dx%d outside the streaming kernel (needs W %% 4 == 0, W >= 128)", B, Cin, H, W);
+        return PWC_EUNSUPPORTED;
+    }
+    const float *w_raw = static_cast<const float *>(head_wp) + mfma_image_floats(Cin, 2);
+    const int rc = pwc_conv::stream3x3_head_upfeat(xf, B, Cin, H, W, x_bstride, w_raw, static_cast<const float *>(head_bias),
+                                                   static_cast<float *>(flow), flow_bstride, static_cast<const float *>(up_w),
+                                                   static_cast<const float *>(up_bias), static_cast<float *>(up_out), up_bstride,
+                                                   static_cast<hipStream_t>(stream));
+    if (rc == PWC_EUNSUPPORTED) pwc::set_error("pwc_head_upfeat_fwd: outputs must be 16-byte aligned");
+    return rc;
 }

@@ -70,7 +70,7 @@ conv3x3_head_kernel(const float *__restrict__ x, const float *__restrict__ w, co
             for (int c = 0; c < 3; ++c) v[a][c] = xp[off[a][c]] * msk[a][c];
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
-            const float *wk = w + ((int64_t)co * Cin + ci) * 9;          // wave-uniform
+            const float *wk = w + (int64_t)ci * 20 + co * 10;               // wave-uniform; tail layout [ci][co][10]
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll

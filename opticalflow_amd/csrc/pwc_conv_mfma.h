@@ -8,32 +8,38 @@
 //   segments of the NCHW output.  The two k of one MFMA are the channel pair (2cp, 2cp+1) at one tap, so
 //   both operands are ds_read_b32 of 32 consecutive dwords per half-wave (conflict-free).
 //
-// Workgroup = 4 waves, one per SIMD, one workgroup per CU (the accumulators may use the whole 512-entry
-// register file).  Tile = (4*NT rows x 32 cols) pixels x (32*MT) couts; wave w owns rows w*NT..w*NT+NT-1.
-// Cin is consumed in chunks of 8 through a DOUBLE-BUFFERED LDS image
-//     input tile  [8][rows+halo][cols+halo]   flat, dword granular      (tap = address offset: no im2col)
-//     weights     [8][9 taps][32*MT couts]                               (from the packed [chunk][c][tap][CoutP])
+// Workgroup = 4 waves (one per SIMD).  Tile = (4*NT rows x 32 cols) pixels x (32*MT) couts; wave w owns rows
+// w*NT..w*NT+NT-1.  Cin is consumed in chunks of CK channels through a DOUBLE-BUFFERED LDS image
+//     input tile  [CK][rows+halo][cols+halo]   flat, dword granular     (tap = address offset: no im2col)
+//     weights     [CK][9 taps][32*MT couts]                              (from the packed [cin][tap][CoutP])
 // filled ONLY by buffer_load ... lds (LDS-DMA): no staging VGPRs, no VALU in the loop.  Each lane's source
 // offset is computed once per workgroup; zero padding, ragged image edges and the ragged last channel
 // chunk all come from the buffer range check (out-of-range lanes deliver 0 to LDS).  Chunk k+1 streams in
-// while chunk k's 36*MT*NT MFMAs run; one barrier per chunk.
+// while chunk k's MFMAs run; one barrier per chunk.
+//
+// Two residency variants per tile shape (TWO):
+//   TWO=0: CK=8, one workgroup per CU, accumulators may use the whole 512-entry register file (MT*NT <= 16);
+//   TWO=1: CK=4, <=256 registers and <=80 KiB LDS so that TWO workgroups share a CU (MT*NT <= 8): the second
+//          workgroup's MFMAs cover the first one's barrier / DMA issue / prologue / epilogue.  Measured
+//          (profiles/r01_conv_notes.md): with one workgroup per CU ~13-30 us per workgroup are uncovered,
+//          which costs short-K layers (conv2_0: 15 chunks) 29 % of the MFMA peak.
 #pragma once
+#include <stdlib.h>
+
 #include "pwc_common.h"
 
 namespace pwc_conv {
 
-using pwc::from_f32;
 using pwc::leaky;
-using pwc::to_f32;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int kCK = 8;            // input channels per chunk
+constexpr int kPackCK = 8;        // packed weights are zero-padded to a multiple of 8 input channels
 constexpr int kThreads = 256;     // 4 waves
 constexpr int kTileW = 32;        // = MFMA N
 constexpr unsigned kOOB = 0x80000000u;   // voffset that always fails the range check -> LDS gets 0
-constexpr int kRsrcFlags = 0x00020000;   // raw buffer, 32-bit elements irrelevant (offen addressing)
+constexpr int kRsrcFlags = 0x00020000;
 
 __device__ __forceinline__ void *uniform_ptr(const void *p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -42,8 +48,10 @@ __device__ __forceinline__ void *uniform_ptr(const void *p) {
     return reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
 }
 
-template <int MT, int NT, int S, int D>
+template <int MT, int NT, int S, int D, int TWO>
 struct Geom {
+    static constexpr int kCK = TWO ? 4 : 8;                         // input channels per chunk
+    static constexpr int kWPS = TWO ? 2 : 1;                        // waves per SIMD the register budget must allow
     static constexpr int kTileH = 4 * NT;
     static constexpr bool kRowSep = (D >= 16);                      // stage the three ky row-sets separately
     static constexpr int kInW = (kTileW - 1) * S + 2 * D + 1;
@@ -59,19 +67,20 @@ struct Geom {
     static constexpr int kWRegion = kWSlots * kThreads * 4;                       // floats
     static constexpr int kBufFloats = kInRegion + kWRegion;
     static constexpr int kSmemBytes = 2 * kBufFloats * 4;
-    static_assert(kSmemBytes <= 160 * 1024, "tile does not fit the 160 KiB LDS");
-    static_assert(MT * NT <= 16, "accumulators exceed the register file");
+    // does this variant exist?  TWO needs two workgroups' LDS and accumulators + operands within 256 registers
+    static constexpr bool kValid = TWO ? (kSmemBytes <= 80 * 1024 && MT * NT <= 8)
+                                       : (kSmemBytes <= 160 * 1024 && MT * NT <= 16);
 };
 
 namespace {   // kernels and launchers have internal linkage: each translation unit owns its instantiations
 
-// Start the LDS-DMA of one 8-channel chunk (input tile + weight slab) into `buf`.
+// Start the LDS-DMA of one chunk (input tile + weight slab) into `buf`.
 template <class G>
 __device__ __forceinline__ void issue_chunk(const float *xb, const float *wg, int chunk, int Cin, int plane,
                                             int64_t wchunk, unsigned wbytes, int wave, float *buf,
                                             const unsigned (&in_off)[G::kInSlots], const unsigned (&w_off)[G::kWSlots]) {
-    const int c0 = chunk * kCK;
-    const int cvalid = min(kCK, Cin - c0);
+    const int c0 = chunk * G::kCK;
+    const int cvalid = min(G::kCK, Cin - c0);
     // descriptors built from readfirstlane'd words so hipcc can prove them wave-uniform
     // (otherwise every DMA is wrapped in a waterfall loop)
     __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
@@ -88,13 +97,14 @@ __device__ __forceinline__ void issue_chunk(const float *xb, const float *wg, in
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dst_w + j * kThreads * 4), 16, w_off[j], 0, 0, 0);
 }
 
-template <int MT, int NT, int S, int D>
-__global__ void __launch_bounds__(kThreads, 1)
+template <int MT, int NT, int S, int D, int TWO>
+__global__ void __launch_bounds__(kThreads, (TWO ? 2 : 1))
 conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                     const float *__restrict__ residual, float *__restrict__ y,
                     int Cin, int H, int W, int Cout, int CoutP, int Ho, int Wo, int tiles_x, int tiles_y,
                     int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky) {
-    using G = Geom<MT, NT, S, D>;
+    using G = Geom<MT, NT, S, D, TWO>;
+    constexpr int CK = G::kCK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
@@ -155,8 +165,8 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     }
 
     const float *xb = x + (int64_t)b * bsx;
-    const int nchunks = (Cin + kCK - 1) / kCK;
-    const int64_t wchunk = (int64_t)kCK * 9 * CoutP;            // floats per packed chunk
+    const int nchunks = (Cin + CK - 1) / CK;
+    const int64_t wchunk = (int64_t)CK * 9 * CoutP;             // floats per chunk of the packed [cin][tap][CoutP]
     const float *wg = wp + g * G::kCoutT;                       // this workgroup's cout columns
     const unsigned wbytes = (unsigned)(wchunk - g * G::kCoutT) * 4u;
 
@@ -178,7 +188,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-            for (int cp = 0; cp < kCK / 2; ++cp) {
+            for (int cp = 0; cp < CK / 2; ++cp) {
                 float a[MT], bv[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a[mt] = rd_w[(cp * 2 * 9 + tap) * G::kCoutT + mt * 32];
@@ -231,47 +241,82 @@ struct ConvArgs {
 
 namespace {
 
-template <int MT, int NT, int S, int D>
+template <int MT, int NT, int S, int D, int TWO>
 int launch(const ConvArgs &a) {
-    using G = Geom<MT, NT, S, D>;
-    const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
-    const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
-    const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
-    const int groups = (a.CoutP / 32 + MT - 1) / MT;
-    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: grid too large");
-    auto kern = conv3x3_mfma_kernel<MT, NT, S, D>;
-    static bool attr_set = false;   // one per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kSmemBytes);
-        if (e != hipSuccess)
-            PWC_FAIL((int)e, "pwc_conv2d_fwd: hipFuncSetAttribute(%d B LDS): %s", G::kSmemBytes, hipGetErrorString(e));
-        attr_set = true;
+    using G = Geom<MT, NT, S, D, TWO>;
+    if constexpr (!G::kValid) {
+        PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: internal: tile %dx%d two=%d does not exist", MT, NT, TWO);
+    } else {
+        const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+        const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
+        const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
+        const int groups = (a.CoutP / 32 + MT - 1) / MT;
+        if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: grid too large");
+        auto kern = conv3x3_mfma_kernel<MT, NT, S, D, TWO>;
+        static bool attr_set = false;   // one per instantiation
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kSmemBytes);
+            if (e != hipSuccess)
+                PWC_FAIL((int)e, "pwc_conv2d_fwd: hipFuncSetAttribute(%d B LDS): %s", G::kSmemBytes, hipGetErrorString(e));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
+                           a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
+                           tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky);
+        return pwc::check_launch("conv3x3_mfma_kernel");
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
-                       a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
-                       tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky);
-    return pwc::check_launch("conv3x3_mfma_kernel");
 }
 
-// (MT, NT) choice: fewest "rounds x per-block work" on 256 CUs, one workgroup per CU.
-//   work per block per chunk ~ MT*NT MFMA tile-steps + ~0.35 of fixed cost (barrier, DMA issue, drain)
-struct TileChoice { int mt, nt; };
-inline TileChoice choose_tile(int B, int Ho, int Wo, int CoutP, int max_nt, int max_mt) {
+// (MT, NT, TWO) choice by a cost model fitted to measurements on MI355X (time in units of one MFMA
+// tile-step over 8 channels ~ 1 us):
+//   one workgroup per CU  : ceil(blocks/256) * (chunks8 * (MT*NT + 0.45) + 20)
+//   two workgroups per CU : (blocks/512 + 0.25) * (chunks8 * 2*MT*NT + 5)        (blocks > 512)
+// (sweep of 13 variants x 7 level-2 layers at batch 16: profiles/r01_conv_notes.md)
+struct TileChoice { int mt, nt, two; };
+
+template <int S, int D>
+constexpr bool variant_valid(int mt, int nt, int two) {
+#define PWC_V(MT_, NT_) if (mt == MT_ && nt == NT_) return two ? Geom<MT_, NT_, S, D, 1>::kValid : Geom<MT_, NT_, S, D, 0>::kValid;
+    PWC_V(1, 1) PWC_V(2, 1) PWC_V(3, 1) PWC_V(4, 1) PWC_V(1, 2) PWC_V(2, 2) PWC_V(3, 2) PWC_V(4, 2)
+    PWC_V(1, 4) PWC_V(2, 4) PWC_V(3, 4) PWC_V(4, 4)
+#undef PWC_V
+    return false;
+}
+
+template <int S, int D>
+inline TileChoice choose_tile(int B, int Cin, int Ho, int Wo, int CoutP, int max_nt, int max_mt, int force_two) {
     const int tiles32 = CoutP / 32;
     const int tiles_x = (Wo + kTileW - 1) / kTileW;
-    TileChoice best{1, 1};
+    const double chunks8 = (Cin + 7) / 8;
+    TileChoice best{1, 1, 0};
     double best_cost = 1e300;
-    for (int mt = 1; mt <= max_mt; ++mt) {
-        if (mt > tiles32) break;
-        const int groups = (tiles32 + mt - 1) / mt;
-        for (int nt = 1; nt <= max_nt; nt *= 2) {
-            if (mt * nt > 16) continue;
-            const int tiles_y = (Ho + 4 * nt - 1) / (4 * nt);
-            const double blocks = (double)B * tiles_x * tiles_y * groups;
-            const double rounds = (double)(int64_t)((blocks + 255) / 256);
-            const double cost = rounds * (mt * nt + 0.35) * (1.0 + 0.02 * groups);   // mild penalty: input re-read per group
-            if (cost < best_cost) { best_cost = cost; best = {mt, nt}; }
+    for (int two = 0; two <= 1; ++two) {
+        if (force_two >= 0 && two != force_two) continue;
+        for (int mt = 1; mt <= max_mt; ++mt) {
+            if (mt > tiles32) break;
+            const int groups = (tiles32 + mt - 1) / mt;
+            for (int nt = 1; nt <= max_nt; nt *= 2) {
+                if (!variant_valid<S, D>(mt, nt, two)) continue;
+                const int tiles_y = (Ho + 4 * nt - 1) / (4 * nt);
+                const double blocks = (double)B * tiles_x * tiles_y * groups;
+                double cost;
+                if (!two) {
+                    // equal-length workgroups, one per CU: discrete rounds
+                    const double rounds = (double)(int64_t)((blocks + 255.0) / 256.0);
+                    cost = rounds * (chunks8 * (mt * nt + 0.45) + 20.0);
+                } else if (blocks <= 256.0) {
+                    cost = chunks8 * (mt * nt + 0.75) + 20.0;      // alone on its CU, twice the barriers (CK=4)
+                } else if (blocks <= 512.0) {
+                    cost = chunks8 * 2.0 * mt * nt + 5.0;           // the busiest CU holds two
+                } else {
+                    // workgroups retire and start independently: work / throughput + a quarter-round tail
+                    cost = (blocks / 512.0 + 0.25) * (chunks8 * 2.0 * mt * nt + 5.0);
+                    if (mt == 3) cost *= 1.12;                      // measured: the 96-wide variant under-performs here
+                }
+                cost *= 1.0 + 0.02 * (groups - 1);               // mild penalty: input re-read per cout group
+                if (cost < best_cost) { best_cost = cost; best = {mt, nt, two}; }
+            }
         }
     }
     return best;
@@ -280,8 +325,22 @@ inline TileChoice choose_tile(int B, int Ho, int Wo, int CoutP, int max_nt, int 
 // one of these per translation unit
 template <int S, int D, int MAXNT, int MAXMT>
 int dispatch(const ConvArgs &a) {
-    const TileChoice t = choose_tile(a.B, a.Ho, a.Wo, a.CoutP, MAXNT, MAXMT);
-#define PWC_TILE(MT_, NT_) if (t.mt == MT_ && t.nt == NT_) return launch<MT_, NT_, S, D>(a);
+    static const int force_two = [] { const char *e = getenv("PWC_CONV_TWO"); return (e && *e) ? atoi(e) : -1; }();
+    TileChoice t = choose_tile<S, D>(a.B, a.Cin, a.Ho, a.Wo, a.CoutP, MAXNT, MAXMT, force_two);
+    if (force_two >= 0 && !variant_valid<S, D>(t.mt, t.nt, t.two))
+        t = choose_tile<S, D>(a.B, a.Cin, a.Ho, a.Wo, a.CoutP, MAXNT, MAXMT, -1);
+    // tuning knob: PWC_CONV_TILE="mt,nt,two" overrides the model when that variant exists for this layer
+    static const TileChoice forced = [] {
+        TileChoice f{0, 0, 0};
+        const char *e = getenv("PWC_CONV_TILE");
+        if (e) sscanf(e, "%d,%d,%d", &f.mt, &f.nt, &f.two);
+        return f;
+    }();
+    if (forced.mt > 0 && forced.mt <= MAXMT && forced.nt <= MAXNT && forced.mt * 32 <= a.CoutP + 31 &&
+        variant_valid<S, D>(forced.mt, forced.nt, forced.two))
+        t = forced;
+#define PWC_TILE(MT_, NT_)                                                                       \
+    if (t.mt == MT_ && t.nt == NT_) return t.two ? launch<MT_, NT_, S, D, 1>(a) : launch<MT_, NT_, S, D, 0>(a);
     PWC_TILE(1, 1) PWC_TILE(2, 1) PWC_TILE(3, 1)
     PWC_TILE(1, 2) PWC_TILE(2, 2) PWC_TILE(3, 2)
     if constexpr (MAXMT >= 4) { PWC_TILE(4, 1) PWC_TILE(4, 2) }

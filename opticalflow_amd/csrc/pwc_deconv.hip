@@ -7,17 +7,23 @@
 // Input-anchored: a lane owns one input pixel and produces the 2x2 output quad it anchors from its 3x3
 // neighbourhood, so every input value is loaded once per lane and reused by 4 outputs x 2 couts.  The
 // reduction over Cin is split across the 8 waves of the workgroup (wave w takes channels w, w+8, ...), which
-// all cover the SAME 4x16 pixel tile; partial sums meet in LDS.  That keeps ~600-channel upfeat layers from
+// all cover the SAME 8x8 pixel tile; partial sums meet in LDS.  That keeps ~600-channel upfeat layers from
 // being one long serial loop per thread (the first version ran 300 us per call regardless of level).
 // Weights are wave-uniform (scalar loads).  fp32 only.
 #include "pwc_common.h"
+
+namespace pwc_conv {
+bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx);
+int stream3x3_upfeat(const float *x, const float *w, const float *bias, float *y,
+                     int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, hipStream_t st);
+}  // namespace pwc_conv
 
 namespace {
 
 constexpr int kDWaves = 8;
 constexpr int kDThreads = 64 * kDWaves;
-constexpr int kDTH = 4;              // 4 rows x 16 cols of input pixels per workgroup (64-byte row segments)
-constexpr int kDTW = 16;
+constexpr int kDTH = 8;              // 8 x 8 input pixels per workgroup
+constexpr int kDTW = 8;
 
 template <int CO>
 __global__ void __launch_bounds__(kDThreads)
@@ -34,8 +40,8 @@ deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, con
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int iy = ty * kDTH + (lane >> 4);
-    const int ix = tx * kDTW + (lane & 15);
+    const int iy = ty * kDTH + (lane >> 3);
+    const int ix = tx * kDTW + (lane & 7);
     const int64_t plane = (int64_t)H * W;
     const float *xb = x + (int64_t)b * bsx;
 
@@ -56,7 +62,6 @@ deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, con
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[co][0][0] = acc[co][0][1] = acc[co][1][0] = acc[co][1][1] = 0.f;
 
-#pragma unroll 4
     for (int ci = wave; ci < Cin; ci += kDWaves) {
         const float *xp = xb + (int64_t)ci * plane;
         float v[3][3];
@@ -109,6 +114,13 @@ extern "C" int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bia
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_deconv4x4s2_fwd: bad shape");
     if (Cout != 2) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_deconv4x4s2_fwd: Cout=%d (PWC-Net only has 2-channel deconvs)", Cout);
     if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_deconv4x4s2_fwd: dtype %d", dtype);
+    // wide images with many channels: stream the input through the LDS ring (pwc_stream3x3.hip)
+    if (Cin >= 16 && pwc_conv::stream3x3_ok(B, Cin, H, W, x, x_bstride)) {
+        const int rc = pwc_conv::stream3x3_upfeat(static_cast<const float *>(x), static_cast<const float *>(w),
+                                                  static_cast<const float *>(bias), static_cast<float *>(y), B, Cin, H, W,
+                                                  x_bstride, y_bstride, static_cast<hipStream_t>(stream));
+        if (rc != PWC_EUNSUPPORTED) return rc;
+    }
     const int tiles_x = (W + kDTW - 1) / kDTW;
     const int tiles_y = (H + kDTH - 1) / kDTH;
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;

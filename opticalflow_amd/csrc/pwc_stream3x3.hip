@@ -1,0 +1,287 @@
+// Streaming 3x3-window kernel for the 2-channel layers that read a whole dense-block arena:
+//   HEAD   : predict_flowL = Conv2d(Cin, 2, 3x3, pad 1)                (reference models/PWCNet.py:32-33)
+//   UPFEAT : upfeatL / deconvL = ConvTranspose2d(Cin, 2, k4, s2, p1)   (PWCNet.py:35-36)
+// Both consume the SAME 3x3 input window per pixel, produce only 2 channels and are bound by streaming
+// [B,Cin,H,W] from HBM once (1 GB for predict_flow2 at batch 16), so they share one structure and can run
+// FUSED in one pass over the arena (mode HEAD|UPFEAT: predict_flowL + upfeatL, PWCNet.py:207+209 etc.).
+//
+//   * workgroup = 256 threads = an 8-row x 128-col tile of input pixels; thread = 4 consecutive pixels;
+//   * the tile (+1 halo; columns start 4 left of the tile so every 16-byte piece is aligned) streams per
+//     4-channel chunk through a 4-deep LDS ring filled by buffer_load_dwordx4 ... lds issued from inline asm
+//     (pwc_common.h): three chunks in flight, counted vmcnt, one barrier per chunk; zero padding and the ragged
+//     last chunk come from the buffer range check;
+//   * the chunk's filter taps travel in the SAME ring slot (the DMA instruction slot that waves 2 and 3 would
+//     otherwise spend on padding carries 80 + 128 floats of weights), and are read back as LDS broadcasts:
+//     with one wave per SIMD, per-channel scalar loads from global were fully exposed (3x slower);
+//   * per channel a thread reads its 3 x 6 window (ds_read_b128 + 2 ds_read_b32 per row) and does
+//     72 fma (HEAD) and/or 128 fma (UPFEAT);
+//   * epilogue: bias, optional LeakyReLU / residual (HEAD), 16-byte stores.
+// Needs W % 4 == 0, W >= 128 and 16-byte aligned tensors; the dispatchers in pwc_conv.hip / pwc_deconv.hip
+// use other kernels otherwise.
+#include "pwc_common.h"
+
+namespace {
+
+using pwc::leaky;
+
+constexpr int kCK = 4;                  // channels per chunk
+constexpr int kRing = 4;
+constexpr int kTH = 8;
+constexpr int kTW = 128;
+constexpr int kThreads = 256;
+constexpr int kRows = kTH + 2;
+constexpr int kPitch = kTW + 8;         // floats: cols x0-4 .. x0+131
+constexpr int kQuads = kPitch / 4;      // 34 pieces per row
+constexpr int kPieces = kCK * kRows * kQuads;                   // 1360
+constexpr int kSlots = (kPieces + kThreads - 1) / kThreads;     // 6 per thread (all waves issue 6: uniform count)
+constexpr int kBuf = kSlots * kThreads * 4;                     // 6144 floats = 24 KiB per ring slot
+constexpr int kHeadWOff = (kSlots - 1) * kThreads * 4 + 2 * 256;    // floats: wave 2's last-slot strip (5632)
+constexpr int kUpWOff = (kSlots - 1) * kThreads * 4 + 3 * 256;      // floats: wave 3's last-slot strip (5888)
+constexpr int kHeadWRow = 20;           // packed head taps per channel: {co0: 9 taps, 0, co1: 9 taps, 0}
+constexpr int kUpWRow = 32;             // nn layout [ci][co][4][4]
+constexpr unsigned kOOB = 0x80000000u;
+static_assert(kPieces * 4 <= kHeadWOff, "weights strip overlaps the tile");
+
+constexpr int MODE_HEAD = 1, MODE_UPFEAT = 2;
+
+template <int MODE>
+__device__ __forceinline__ void issue(const float *xb, const float *hw, const float *uw, int chunk, int Cin, int plane,
+                                      int wave, float *buf, const unsigned (&off)[kSlots]) {
+    const int c0 = chunk * kCK;
+    const int cvalid = min(kCK, Cin - c0);
+    const pwc::v4i32 r = pwc::make_rsrc(xb + (int64_t)c0 * plane, cvalid * plane * 4);
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf)) + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < kSlots - 1; ++j) pwc::dma_b128(r, base + j * (kThreads * 16), off[j]);
+    // last slot: waves 0,1 finish the tile; waves 2,3 (whose pieces would be padding) fetch this chunk's taps
+    const unsigned last = base + (kSlots - 1) * (kThreads * 16);
+    if (wave == 2 && (MODE & MODE_HEAD)) {
+        pwc::dma_b128(pwc::make_rsrc(hw + (int64_t)c0 * kHeadWRow, cvalid * kHeadWRow * 4), last, off[kSlots - 1]);
+    } else if (wave == 3 && (MODE & MODE_UPFEAT)) {
+        pwc::dma_b128(pwc::make_rsrc(uw + (int64_t)c0 * kUpWRow, cvalid * kUpWRow * 4), last, off[kSlots - 1]);
+    } else {
+        pwc::dma_b128(r, last, off[kSlots - 1]);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreads)
+stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x, int tiles_y, int64_t bsx,
+                 // HEAD: w packed [Cin][20], y [B,2,H,W]
+                 const float *__restrict__ hw, const float *__restrict__ hbias, const float *__restrict__ residual,
+                 float *__restrict__ hy, int64_t bshy, int64_t bsr, float slope, int do_leaky,
+                 // UPFEAT: w [Cin][2][16], y [B,2,2H,2W]
+                 const float *__restrict__ uw, const float *__restrict__ ubias, float *__restrict__ uy, int64_t bsuy) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int ty = tid >> 5;            // 0..7  row inside the tile
+    const int tx = tid & 31;            // 0..31 group of 4 pixels
+    int bid = blockIdx.x;
+    const int bx = bid % tiles_x;
+    bid /= tiles_x;
+    const int by = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = bx * kTW;
+    const int y0 = by * kTH;
+    const int plane = H * W;
+
+    unsigned off[kSlots];
+#pragma unroll
+    for (int j = 0; j < kSlots; ++j) {
+        const int p = j * kThreads + tid;
+        const int c = p / (kRows * kQuads);
+        const int rem = p % (kRows * kQuads);
+        const int r = rem / kQuads;
+        const int q = rem % kQuads;
+        const int iy = y0 - 1 + r;
+        const int ix = x0 - 4 + 4 * q;
+        const bool ok = (p < kPieces) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);   // W % 4 == 0
+        off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+    }
+    // the weight fetches of waves 2 / 3 are plain contiguous copies: lane -> 16-byte piece `lane`
+    if (wave == 2 && (MODE & MODE_HEAD)) off[kSlots - 1] = (lane < kCK * kHeadWRow / 4) ? lane * 16u : kOOB;
+    if (wave == 3 && (MODE & MODE_UPFEAT)) off[kSlots - 1] = (lane < kCK * kUpWRow / 4) ? lane * 16u : kOOB;
+
+    float hacc[2][4];                   // HEAD:   [co][px]
+    float uacc[2][2][8];                // UPFEAT: [co][out row parity][out col 0..7] (8 output cols for 4 input px)
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) hacc[co][p] = 0.f;
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) uacc[co][py][k] = 0.f;
+    }
+
+    const float *xb = x + (int64_t)b * bsx;
+    const int nchunks = (Cin + kCK - 1) / kCK;
+#pragma unroll
+    for (int k = 0; k < kRing - 1; ++k)
+        if (k < nchunks) issue<MODE>(xb, hw, uw, k, Cin, plane, wave, smem + k * kBuf, off);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int ahead = min(kRing - 2, nchunks - 1 - chunk);
+        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kSlots) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSlots) : "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (chunk + kRing - 1 < nchunks)
+            issue<MODE>(xb, hw, uw, chunk + kRing - 1, Cin, plane, wave, smem + ((chunk + kRing - 1) % kRing) * kBuf, off);
+        const float *cur = smem + (chunk % kRing) * kBuf;
+        // channels past Cin in the last chunk: tile AND taps were range-checked to 0, so they add exactly 0
+#pragma unroll
+        for (int c = 0; c < kCK; ++c) {
+            const float *t = cur + (c * kRows + ty) * kPitch + 4 * tx + 3;     // window col -1
+            float v[3][6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float *row = t + r * kPitch;
+                const float4 m = *reinterpret_cast<const float4 *>(row + 1);
+                v[r][0] = row[0];
+                v[r][1] = m.x; v[r][2] = m.y; v[r][3] = m.z; v[r][4] = m.w;
+                v[r][5] = row[5];
+            }
+            if constexpr (MODE & MODE_HEAD) {
+                const float4 *wq = reinterpret_cast<const float4 *>(cur + kHeadWOff + c * kHeadWRow);   // LDS broadcast
+                const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2], q3 = wq[3], q4 = wq[4];
+                const float wk[2][9] = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x},
+                                        {q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z}};
+#pragma unroll
+                for (int co = 0; co < 2; ++co)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) hacc[co][p] = fmaf(v[ky][p + kx], wk[co][ky * 3 + kx], hacc[co][p]);
+            }
+            if constexpr (MODE & MODE_UPFEAT) {
+                // oy = 2*iy' - 1 + ky: out row 2*iy+py takes py=0: (iy-1,ky=3),(iy,ky=1); py=1: (iy,ky=2),(iy+1,ky=0)
+                // window row index a: iy-1+a ; window col index e: ix-1+e, pixel p sits at e = p+1
+                const float4 *wq = reinterpret_cast<const float4 *>(cur + kUpWOff + c * kUpWRow);       // LDS broadcast
+#pragma unroll
+                for (int co = 0; co < 2; ++co) {
+                    const float4 k0 = wq[co * 4 + 0], k1 = wq[co * 4 + 1], k2 = wq[co * 4 + 2], k3 = wq[co * 4 + 3];
+                    const float k[16] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w,
+                                         k2.x, k2.y, k2.z, k2.w, k3.x, k3.y, k3.z, k3.w};        // k[ky*4 + kx]
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        const int kya = py ? 2 : 3, kyb = py ? 0 : 1;        // window rows a = py, py+1
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                            for (int px = 0; px < 2; ++px) {
+                                const int kxa = px ? 2 : 3, kxb = px ? 0 : 1;    // window cols e = p+px, p+px+1
+                                float s = uacc[co][py][2 * p + px];
+                                s = fmaf(v[py][p + px], k[kya * 4 + kxa], s);
+                                s = fmaf(v[py][p + px + 1], k[kya * 4 + kxb], s);
+                                s = fmaf(v[py + 1][p + px], k[kyb * 4 + kxa], s);
+                                s = fmaf(v[py + 1][p + px + 1], k[kyb * 4 + kxb], s);
+                                uacc[co][py][2 * p + px] = s;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS reads done before the ring slot is refilled
+    }
+
+    const int oy = y0 + ty;
+    const int ox = x0 + 4 * tx;
+    if (oy >= H || ox >= W) return;
+    if constexpr (MODE & MODE_HEAD) {
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+            const int64_t o = (int64_t)co * plane + (int64_t)oy * W + ox;
+            const float bv = hbias[co];
+            float4 v = make_float4(hacc[co][0] + bv, hacc[co][1] + bv, hacc[co][2] + bv, hacc[co][3] + bv);
+            if (do_leaky) { v.x = leaky(v.x, slope); v.y = leaky(v.y, slope); v.z = leaky(v.z, slope); v.w = leaky(v.w, slope); }
+            if (residual) {
+                const float4 rr = *reinterpret_cast<const float4 *>(residual + (int64_t)b * bsr + o);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            *reinterpret_cast<float4 *>(hy + (int64_t)b * bshy + o) = v;
+        }
+    }
+    if constexpr (MODE & MODE_UPFEAT) {
+        const int Wo = 2 * W;
+#pragma unroll
+        for (int co = 0; co < 2; ++co) {
+            const float bv = ubias[co];
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                float *p = uy + (int64_t)b * bsuy + (int64_t)co * 4 * plane + (int64_t)(2 * oy + py) * Wo + 2 * ox;
+                *reinterpret_cast<float4 *>(p) = make_float4(uacc[co][py][0] + bv, uacc[co][py][1] + bv,
+                                                             uacc[co][py][2] + bv, uacc[co][py][3] + bv);
+                *reinterpret_cast<float4 *>(p + 4) = make_float4(uacc[co][py][4] + bv, uacc[co][py][5] + bv,
+                                                                 uacc[co][py][6] + bv, uacc[co][py][7] + bv);
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch(const float *x, int B, int Cin, int H, int W, int64_t bsx,
+           const float *hw, const float *hbias, const float *residual, float *hy, int64_t bshy, int64_t bsr,
+           float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
+    const int tiles_x = (W + kTW - 1) / kTW;
+    const int tiles_y = (H + kTH - 1) / kTH;
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "stream3x3: grid too large");
+    constexpr int smem = kRing * kBuf * 4;      // 96 KiB
+    auto kern = stream3x3_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) PWC_FAIL((int)e, "stream3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), smem, st,
+                       x, Cin, H, W, tiles_x, tiles_y, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky,
+                       uw, ubias, uy, bsuy);
+    return pwc::check_launch("stream3x3_kernel");
+}
+
+inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+namespace pwc_conv {
+
+// true when the streaming kernel applies to this geometry (the callers keep their other kernels otherwise)
+bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx) {
+    return (W % 4 == 0) && (W >= 128) && al16(x) && (bsx % 4 == 0) && ((int64_t)H * W * kCK * 4 < 0x7fffffffLL) &&
+           (int64_t)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) >= 64;
+}
+
+// w = packed head taps [Cin][20] (tail of pwc_conv3x3_pack's buffer for Cout == 2)
+int stream3x3_head(const float *x, const float *w, const float *bias, const float *residual, float *y,
+                   int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, int64_t bsr,
+                   float slope, int do_leaky, hipStream_t st) {
+    if (!al16(y) || (bsy % 4) || !al16(w) || (residual && (!al16(residual) || (bsr % 4)))) return PWC_EUNSUPPORTED;
+    return launch<MODE_HEAD>(x, B, Cin, H, W, bsx, w, bias, residual, y, bsy, bsr, slope, do_leaky,
+                             nullptr, nullptr, nullptr, 0, st);
+}
+
+// w = nn.ConvTranspose2d weight [Cin][2][4][4]
+int stream3x3_upfeat(const float *x, const float *w, const float *bias, float *y,
+                     int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, hipStream_t st) {
+    if (!al16(y) || (bsy % 4) || !al16(w)) return PWC_EUNSUPPORTED;
+    return launch<MODE_UPFEAT>(x, B, Cin, H, W, bsx, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0,
+                               w, bias, y, bsy, st);
+}
+
+int stream3x3_head_upfeat(const float *x, int B, int Cin, int H, int W, int64_t bsx,
+                          const float *hw, const float *hbias, float *hy, int64_t bshy,
+                          const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
+    if (!al16(hy) || (bshy % 4) || !al16(uy) || (bsuy % 4) || !al16(hw) || !al16(uw)) return PWC_EUNSUPPORTED;
+    return launch<MODE_HEAD | MODE_UPFEAT>(x, B, Cin, H, W, bsx, hw, hbias, nullptr, hy, bshy, 0, 0.f, 0,
+                                           uw, ubias, uy, bsuy, st);
+}
+
+}  // namespace pwc_conv

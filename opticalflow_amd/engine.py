@@ -161,13 +161,22 @@ class PwcPlan:
             for i, (co, off_i) in enumerate(zip(DENSE_OUT, DENSE_OFF)):
                 self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, off_i:off_i + co])
                 lo = off_i
-            self._conv("predict_flow%d" % l, ar, self.flow[l], act=False)
-            if l > 2:
+            if l == 2:
+                self._conv("predict_flow2", ar, self.flow[2], act=False)
+            else:
                 nxt = self.arena[l - 1]
                 cn = PYRAMID_CH[l - 1]
                 o = base + nd + cn
+                h, w = self.size[l]
+                if self.conv_backend == "hip" and ops.head_upfeat_supported(self.B, h, w):
+                    # predict_flowL and upfeatL read the same 3x3 windows of the same arena: one pass
+                    ops.head_upfeat(ar, self.packed["predict_flow%d" % l], self.p["predict_flow%d.bias" % l],
+                                    self.p["upfeat%d.weight" % l], self.p["upfeat%d.bias" % l],
+                                    self.flow[l], nxt[:, o + 2:o + 4])
+                else:
+                    self._conv("predict_flow%d" % l, ar, self.flow[l], act=False)
+                    self._deconv("upfeat%d" % l, ar, nxt[:, o + 2:o + 4])
                 self._deconv("deconv%d" % l, self.flow[l], nxt[:, o:o + 2])
-                self._deconv("upfeat%d" % l, ar, nxt[:, o + 2:o + 4])
         # -- context network (PWCNet.py:267-268) ------------------------------------------------------
         t = self.arena[2]
         for i, (_, dil) in enumerate(CONTEXT):

@@ -190,6 +190,33 @@ def conv3x3(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cout: in
     return out
 
 
+def head_upfeat_supported(B: int, H: int, W: int) -> bool:
+    """Geometry gate of pwc_head_upfeat_fwd (mirrors stream3x3_ok in csrc/pwc_stream3x3.hip)."""
+    return W % 4 == 0 and W >= 128 and B * ((W + 127) // 128) * ((H + 7) // 8) >= 64
+
+
+def head_upfeat(x: torch.Tensor, head_wpacked: torch.Tensor, head_bias: torch.Tensor, up_weight: torch.Tensor,
+                up_bias: torch.Tensor, flow_out: torch.Tensor, up_out: torch.Tensor) -> None:
+    """predict_flowL + upfeatL in one pass over the arena x (fused C-ABI entry pwc_head_upfeat_fwd)."""
+    lib = _lib.load()
+    bsx = _plane_dense(x, "x")
+    B, cin, H, W = x.shape
+    if tuple(flow_out.shape) != (B, 2, H, W) or tuple(up_out.shape) != (B, 2, 2 * H, 2 * W):
+        raise ValueError("flow_out must be %s and up_out %s" % ((B, 2, H, W), (B, 2, 2 * H, 2 * W)))
+    if tuple(up_weight.shape) != (cin, 2, 4, 4) or not up_weight.is_contiguous():
+        raise ValueError("up_weight must be contiguous [Cin=%d,2,4,4]" % cin)
+    need = lib.pwc_conv3x3_packed_bytes(cin, 2, PWC_F32)
+    if head_wpacked.numel() * 4 != need:
+        raise ValueError("packed head weights do not match Cin=%d" % cin)
+    bsf = _plane_dense(flow_out, "flow_out")
+    bsu = _plane_dense(up_out, "up_out")
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_head_upfeat_fwd(x.data_ptr(), head_wpacked.data_ptr(), head_bias.data_ptr(), flow_out.data_ptr(),
+                                     up_weight.data_ptr(), up_bias.data_ptr(), up_out.data_ptr(),
+                                     B, cin, H, W, _dtype_code(x), bsx, bsf, bsu, _stream(x))
+    check(rc, "pwc_head_upfeat_fwd")
+
+
 def deconv4x4s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.ConvTranspose2d(k=4, s=2, p=1); weight [Cin,Cout,4,4] float32 contiguous."""

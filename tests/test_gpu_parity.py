@@ -234,6 +234,40 @@ def test_deconv_vs_torch_cpu(dev, cin):
     assert (out[:, :2] == 0).all() and (out[:, 4:] == 0).all()
 
 
+def test_streaming_head_deconv_and_fused_entry(dev):
+    """Wide levels take the LDS-ring streaming kernel (pwc_stream3x3.hip): head, upfeat and the fused call."""
+    from opticalflow_amd import ops
+    B, cin, H, W = 8, 149, 60, 128            # 8 * 8 tiles >= 64, ragged rows (60 = 7.5 tiles), ragged channel chunk
+    assert ops.head_upfeat_supported(B, H, W)
+    x = seeded_rand((B, cin, H, W), 110, -1, 1)
+    hw = seeded_rand((2, cin, 3, 3), 111, -1, 1) * 0.05
+    hb = seeded_rand((2,), 112, -0.5, 0.5)
+    uw = seeded_rand((cin, 2, 4, 4), 113, -1, 1) * 0.05
+    ub = seeded_rand((2,), 114, -0.5, 0.5)
+    res = seeded_rand((B, 2, H, W), 115, -1, 1)
+    torch.set_num_threads(8)
+    ref_h = F.conv2d(x, hw, hb, padding=1)
+    ref_u = F.conv_transpose2d(x, uw, ub, stride=2, padding=1)
+    arena = torch.zeros((B, cin + 7, H, W), device=dev)
+    arena[:, 7:] = x.to(dev)
+    xin = arena[:, 7:]                                         # batch-strided operand
+    hp = ops.pack_conv3x3(hw.to(dev))
+    got_h = ops.conv3x3(xin, hp, hb.to(dev), 2, leaky_slope=None, residual=res.to(dev)).cpu()
+    assert (got_h - (ref_h + res)).abs().max().item() < 2e-4
+    got_l = ops.conv3x3(xin, hp, hb.to(dev), 2, leaky_slope=0.1).cpu()
+    assert (got_l - F.leaky_relu(ref_h, 0.1)).abs().max().item() < 2e-4
+    got_u = ops.deconv4x4s2(xin, uw.to(dev), ub.to(dev)).cpu()
+    assert (got_u - ref_u).abs().max().item() < 2e-4
+    nxt = torch.zeros((B, 9, 2 * H, 2 * W), device=dev)
+    flow = torch.zeros((B, 2, H, W), device=dev)
+    for _ in range(2):
+        ops.head_upfeat(xin, hp, hb.to(dev), uw.to(dev), ub.to(dev), flow, nxt[:, 3:5])
+    assert (flow.cpu() - ref_h).abs().max().item() < 2e-4
+    assert (nxt[:, 3:5].cpu() - ref_u).abs().max().item() < 2e-4
+    assert (nxt[:, :3] == 0).all() and (nxt[:, 5:] == 0).all()
+    assert not ops.head_upfeat_supported(16, 7, 16)
+
+
 # ------------------------------------------------------------------ full forward
 def _golden_net(dev, **kw):
     from opticalflow_amd import PWCDCNet

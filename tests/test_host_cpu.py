@@ -38,7 +38,7 @@ def test_abi_argument_errors_without_gpu():
     assert lib.pwc_corr_fwd(None, None, None, 1, 1, 1, 1, 4, 1, 4, 1, 1, 1.0, 0, 0, 0.0, 1, 1, 1, None) == -1
     assert b"null pointer" in lib.pwc_last_error()
     assert lib.pwc_conv3x3_packed_bytes(565, 128, 0) == 71 * 8 * 9 * 128 * 4
-    assert lib.pwc_conv3x3_packed_bytes(32, 2, 0) == (4 * 8 * 9 * 32 + 2 * 32 * 9) * 4   # MFMA image + raw tail
+    assert lib.pwc_conv3x3_packed_bytes(32, 2, 0) == (4 * 8 * 9 * 32 + 32 * 20) * 4      # MFMA image + [Cin][20] head tail
     assert lib.pwc_conv3x3_packed_bytes(0, 2, 0) == -1
     assert lib.pwc_conv3x3_packed_bytes(8, 8, 1) == -1          # f16 weights not supported
 
