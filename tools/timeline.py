@@ -10,9 +10,9 @@ import sys
 
 
 def short(n):
-    m = re.search(r"conv3x3_mfma_kernel<(\d+), (\d+), (\d+), (\d+)>", n)
+    m = re.search(r"conv3x3_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", n)
     if m:
-        return "mfma<MT%s,NT%s,S%s,D%s>" % m.groups()
+        return "mfma<MT%s,NT%s,S%s,D%s,two%s>" % m.groups()
     for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "warp_kernel", "copyBuffer", "elementwise", "pack3x3"):
         if k in n:
             return k
@@ -24,7 +24,7 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
     starts = [i for i in range(len(rows) - 1)
-              if names[i].endswith("S2,D1>") and names[i + 1] == names[i]
+              if ("S2,D1" in names[i]) and names[i + 1] == names[i]
               and rows[i]["Grid_Size_X"] == rows[i + 1]["Grid_Size_X"] and int(rows[i]["Grid_Size_X"]) > 256 * 1000]
     if len(starts) < 3:
         print("no forward found")
