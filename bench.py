@@ -78,6 +78,19 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PWC_BENCH_CPU_THREADS", "16"))))
 
 
+def pmc_traffic(key, applies):
+    """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and
+    corrected as the MI355X guide prescribes; see profiles/r01_pmc_traffic.json).  Counters cannot be read
+    live, so this is the committed measurement of the same kernel on the same workload, or None."""
+    if not applies:
+        return None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+            return int(json.load(f)[key]["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def event_time_ms(fn, reps, stream):
     """Average duration of fn() over `reps` back-to-back launches, HIP events on the launch stream."""
     start = torch.cuda.Event(enable_timing=True)
@@ -200,9 +213,10 @@ def main():
             flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
             ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
             ach = flops / (ms * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "conv3x3_mfma_kernel<f32,MT=4,S=1,D=1> (dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
+            result["roofline"] = {"kernel": "conv3x3_mfma_kernel<MT=4,NT=1,S=1,D=1,two-per-CU> (dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
                                   "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                  "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                                  "traffic": pmc_traffic("conv3x3_mfma_dc_conv1_b16", B == 16 and (H, W) == (448, 1024)),
                                   "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
         from opticalflow_amd import ops
         c2 = 32
@@ -215,7 +229,8 @@ def main():
         result["roofline_corr"] = {"kernel": "corr81_kernel<f32> (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena write)" % (w2, h2, B),
                                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
-                                   "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
+                                   "traffic": pmc_traffic("corr81_level2_b16", B == 16 and (H, W) == (448, 1024)),
+                                   "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
         if args.conv_backend != "hip":
             result["roofline"] = result["roofline_corr"]
         bytes_warp = (2 * c2 + 2) * h2 * w2 * 4 * B
