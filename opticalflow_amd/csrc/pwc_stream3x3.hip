@@ -25,7 +25,7 @@ namespace {
 using pwc::leaky;
 
 constexpr int kCK = 4;                  // channels per chunk
-constexpr int kRing = 4;
+constexpr int kRing = 3;                // 72 KiB -> two workgroups per CU (a 4th slot measured slower: one WG/CU)
 constexpr int kTH = 8;
 constexpr int kTW = 128;
 constexpr int kThreads = 256;
