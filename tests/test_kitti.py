@@ -1,0 +1,130 @@
+"""KITTI evaluation helpers (opticalflow_amd/kitti.py) against plain statements of inference_kitti.py's semantics."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import seeded_rand
+from oracle import pwc_oracle as O
+from opticalflow_amd import kitti
+
+
+def test_pad_unpad_resize_semantics():
+    x = seeded_rand((1, 6, 375, 1242), 1)
+    xp, ph, pw = kitti.pad_to_64(x)
+    assert (ph, pw) == (9, 38) and xp.shape[-2:] == (384, 1280)
+    assert torch.equal(xp[..., :375, :1242], x)
+    assert torch.equal(xp[..., 380, :1242], x[..., 374, :]) and torch.equal(xp[..., :375, 1270], x[..., :, 1241])   # replicate
+    assert kitti.pad_to_64(x[..., :64, :128])[1:] == (0, 0)
+    f = seeded_rand((1, 2, 96, 320), 2, -1, 1)
+    assert kitti.unpad(f, 9, 38).shape == (1, 2, 87, 282)                      # the reference's full-res crop of the 1/4-res flow
+    r = kitti.flow_resize(f, 375, 1242)
+    ref = F.interpolate(f, size=(375, 1242), mode="bilinear", align_corners=True)
+    assert torch.allclose(r[:, 0], ref[:, 0] * (1242 / 320)) and torch.allclose(r[:, 1], ref[:, 1] * (375 / 96))
+    assert kitti.flow_resize(f, 96, 320) is f
+
+
+def test_metrics_match_bruteforce():
+    rng = np.random.default_rng(0)
+    gt = rng.normal(0, 20, size=(30, 40, 2)).astype(np.float32)
+    pr = gt + rng.normal(0, 2.5, size=gt.shape).astype(np.float32)
+    valid = rng.random((30, 40)) > 0.3
+    e, n, out = 0.0, 0, 0
+    for y in range(30):
+        for x in range(40):
+            if not valid[y, x]:
+                continue
+            d = float(np.hypot(*(pr[y, x] - gt[y, x])))
+            e += d
+            n += 1
+            out += d > max(3.0, 0.05 * float(np.hypot(*gt[y, x])))
+    assert abs(kitti.epe_metric(pr, gt, valid) - e / n) < 1e-5
+    assert abs(kitti.fl_all_metric(pr, gt, valid) - 100.0 * out / n) < 1e-9
+    assert np.isnan(kitti.epe_metric(pr, gt, np.zeros_like(valid))) and np.isnan(kitti.fl_all_metric(pr, gt, np.zeros_like(valid)))
+    assert kitti.fl_all_metric(gt, gt, None) == 0.0
+
+
+def _png_with_filters(arr, filters):
+    """Encode [H,W,3] uint16 with the given per-row PNG filter types (exercises the reader's unfilter paths)."""
+    h, w, _ = arr.shape
+    rows = np.ascontiguousarray(arr, dtype=">u2").reshape(h, -1).view(np.uint8).astype(np.int32)
+    bpp, raw, prev = 6, b"", np.zeros(w * 6, np.int32)
+    for y in range(h):
+        cur, ft = rows[y], filters[y % len(filters)]
+        a = np.concatenate((np.zeros(bpp, np.int32), cur[:-bpp]))
+        c = np.concatenate((np.zeros(bpp, np.int32), prev[:-bpp]))
+        if ft == 0:
+            pred = 0
+        elif ft == 1:
+            pred = a
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (a + prev) >> 1
+        else:
+            pa, pb, pc = np.abs(prev - c), np.abs(a - c), np.abs(a + prev - 2 * c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw += bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_flow_png_codec(tmp_path):
+    rng = np.random.default_rng(1)
+    flow = rng.normal(0, 30, size=(9, 13, 2)).astype(np.float32)
+    flow = np.round(flow * 64) / 64                                   # representable in the 1/64 px code
+    valid = rng.random((9, 13)) > 0.4
+    arr = kitti.encode_flow_rgb16(flow, valid)
+    assert arr.dtype == np.uint16 and arr[0, 0, 0] == int(flow[0, 0, 0] * 64 + 32768)
+    p = str(tmp_path / "f.png")
+    kitti.write_png16_rgb(p, arr)
+    f2, v2 = kitti.load_flow_kitti_png(p)
+    assert np.array_equal(f2, flow) and np.array_equal(v2, valid)
+    open(p, "wb").write(_png_with_filters(arr, [1, 2, 3, 4, 0]))      # every unfilter path of the reader
+    assert np.array_equal(kitti.read_png16_rgb(p), arr)
+    open(p, "wb").write(b"nope")
+    with pytest.raises(ValueError):
+        kitti.read_png16_rgb(p)
+
+
+def test_normalize_pair():
+    im = torch.arange(2 * 3 * 3, dtype=torch.uint8).reshape(2, 3, 3)
+    a, b = kitti.normalize_pair(im, im)
+    assert a.shape == (1, 3, 2, 3) and torch.equal(a, b)
+    ch0 = (im[..., 0].float() / 255 - 0.485) / 0.229
+    assert torch.allclose(a[0, 0], ch0)
+
+
+@pytest.mark.gpu
+def test_model_infer_and_stream_on_gpu(gpu_device):
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    net = PWCDCNet()
+    sd = synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02)
+    net.load_state_dict(sd)
+    net = net.to(gpu_device).eval()
+    rng = np.random.default_rng(2)
+    samples = []
+    for _ in range(3):
+        i1 = torch.from_numpy(rng.integers(0, 256, size=(100, 150, 3), dtype=np.uint8))
+        i2 = torch.from_numpy(rng.integers(0, 256, size=(100, 150, 3), dtype=np.uint8))
+        samples.append((i1, i2))
+    got = [kitti.model_infer(net, a, b).cpu() for a, b in kitti.PairStream(samples, gpu_device)]
+    assert len(got) == 3
+    for (i1, i2), g in zip(samples, got):
+        a, b = kitti.normalize_pair(i1, i2)
+        x, ph, pw = kitti.pad_to_64(torch.cat([a, b], 1))
+        with torch.no_grad():
+            ref = kitti.flow_resize(kitti.unpad(O.pwc_forward(sd, x), ph, pw), 100, 150)
+        assert g.shape == (1, 2, 100, 150)
+        assert O.epe(g, ref) < 1e-3
+    gt = got[0][0].permute(1, 2, 0).numpy()
+    epe, fl, rows = kitti.evaluate_pairs(net, [(s[0], s[1], gt, np.ones((100, 150), bool)) for s in samples[:1]], gpu_device)
+    assert epe < 1e-4 and fl == 0.0 and len(rows) == 1
