@@ -136,11 +136,17 @@ def main():
     _lib.load()                                   # no HIP library -> no benchmark
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no ROCm device is visible")
-    dev = torch.device("cuda", local_rank)
+    # PWC_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- lets the N>1 code path run on a one-GPU box
+    # (a rehearsal of the plumbing, not a measurement; the JSON says so)
+    rehearse = os.environ.get("PWC_BENCH_REHEARSE") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, H, W = args.batch, args.height, args.width
     net = PWCDCNet(conv_backend=args.conv_backend, use_graph=not args.no_graph)
@@ -179,7 +185,7 @@ def main():
     if rank == 0:
         log("timed region: %d steps in %.3f s" % (args.steps, elapsed))
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -205,6 +211,8 @@ def main():
 
     # ---- per-kernel roofline probes (rank 0; HIP events on the launch stream) -----------------------
     if rank == 0:
+        if rehearse:
+            result["config"]["rehearsal"] = "all %d ranks on cuda:0 over gloo: plumbing check, NOT a measurement" % world
         plan = net._plan_for(x)
         stream = torch.cuda.current_stream(dev)
         h2, w2 = H >> 2, W >> 2

@@ -31,7 +31,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> i
     if not tensors:
         return 0
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.broadcast(flat, src=src, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":      # CPU rehearsal of the RCCL path
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat.copy_(host)
+    else:
+        dist.broadcast(flat, src=src, group=group)
     off = 0
     for t in tensors:
         n = t.numel()
@@ -62,10 +67,13 @@ def gather_flows(local: torch.Tensor, counts: List[int], dst: int = 0, group=Non
         pad = local.new_zeros((m - local.shape[0],) + tuple(local.shape[1:]))
         send = torch.cat((local, pad), 0)
     send = send.contiguous()
+    out_device = send.device
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        send = send.cpu()                      # gloo has no device gather (CPU rehearsal of the RCCL path)
     if rank == dst:
         bufs = [torch.empty_like(send) for _ in range(world)]
         dist.gather(send, gather_list=bufs, dst=dst, group=group)
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(out_device)
     dist.gather(send, gather_list=None, dst=dst, group=group)
     return None
 
