@@ -193,32 +193,33 @@ corr81_kernel(const T *__restrict__ in1, const T *__restrict__ in2, T *__restric
     }
 }
 
-// ---- fp32 fast path v2 -------------------------------------------------------------------------------------
+// ---- fp32 fast path v3 -------------------------------------------------------------------------------------
 // Same tile / lane roles as corr81_kernel (wave = dy, lane = 4 pixels x 9 dx), restructured around what the
-// profile showed on MI355X (profiles/r01_corr_ablation.md): the kernel is VALU-bound, not HBM-bound, unless
-// the fma are packed, and load / compute / store phases of a one-tile workgroup do not overlap.
-//   * PERSISTENT workgroups (2 per CU) walk a strided list of tiles; the LDS image is a 4-deep RING of
-//     4-channel chunks filled by buffer_load_dwordx4 ... lds (LDS-DMA) that runs ahead ACROSS tile
-//     boundaries: up to three chunks stream from HBM while one is consumed, and the 16-byte output stores
-//     of tile t drain while tile t+1's chunks are already being multiplied.
+// profiles showed on MI355X (profiles/r01_corr_ablation.md):
+//   * PRODUCER / CONSUMER waves.  A wave's LDS-DMA issue stalls while its older LDS-DMAs are still in flight,
+//     so when the nine fma waves issued the ring's DMA themselves every phase serialised (v2: shell + fma +
+//     loads + stores ~ total).  Now a tenth wave does nothing but run the ring: it issues the 15
+//     buffer_load_dwordx4 ... lds of chunk s+2, waits (counted vmcnt) for chunk s+1, and meets the fma waves
+//     at one barrier per chunk; the fma waves touch VMEM only for their 16-byte output stores.
+//   * PERSISTENT workgroups walk a strided list of tiles and the 3-slot ring runs ahead ACROSS tile
+//     boundaries, so the stores of tile t drain while tile t+1 is already being multiplied.
 //   * v_pk_fma_f32 without repacking: for pixel p the accumulators are paired over dx so that the in2
 //     operand pair (w[p+dx], w[p+dx+1]) starts at an EVEN window index (= an aligned VGPR pair straight
 //     out of ds_read_b128) and in1[p] is broadcast: 4 packed + 1 scalar fma per pixel instead of 9.
-//   * zero padding, ragged edges and the ragged last channel chunk come from the buffer range check; every
-//     wave issues exactly kDmaSlots DMA instructions per chunk (15 real ones dealt round-robin to the 9
-//     waves + 3 all-out-of-range dummies into a spare LDS strip) so "chunk s landed" is a counted vmcnt.
+//   * zero padding, ragged edges and the ragged last channel chunk come from the buffer range check.
 // Needs W % 4 == 0 and 16-byte aligned operands (the launcher falls back to corr81_kernel otherwise).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kCKd = 4;                                   // channels per chunk
-constexpr int kRing = 4;                                  // LDS buffers
+constexpr int kRing = 3;                                  // LDS slots: one consumed, two in flight (2: 76 us, 3: 65 us, 4: 75 us)
 constexpr int kS2Floats = kCKd * kS2Rows * kPitch;        // 2560: in2 halo tile [c][16][40]
 constexpr int kS1Floats = kCKd * kTH * kPitch;            // 1280: in1 tile      [c][8][40] (cols 32..39 unused)
 constexpr int kS2Instr = kS2Floats / 4 / 64;              // 10 wave-instructions of 64 x 16 B
 constexpr int kS1Instr = kS1Floats / 4 / 64;              // 5
-constexpr int kDmaInstr = kS2Instr + kS1Instr;            // 15 real
-constexpr int kDmaSlots = (kDmaInstr + kND - 1) / kND;    // 2 per wave -> 18 issued, 3 dummies
-constexpr int kBufFloats = kDmaSlots * kND * 256;         // 4608 floats = 18 KiB per buffer (incl. dummy strip)
+constexpr int kDmaInstr = kS2Instr + kS1Instr;            // 15 per chunk, all issued by the loader wave
+constexpr int kBufFloats = kS2Floats + kS1Floats;         // 3840 floats = 15 KiB per slot
 constexpr unsigned kOOBv = 0x80000000u;
+constexpr int kLoaderWave = kND;                          // wave 9 (a second loader wave measured slower: 72 vs 65 us)
+constexpr int kThreadsDma = 64 * (kND + 1);               // 640
 constexpr int kPersistentPerCU = 2;
 
 struct TileXY { int b, x0, y0; };
@@ -235,11 +236,10 @@ __device__ __forceinline__ TileXY tile_of(int t, int nblk, int tiles_x, int tile
     return r;
 }
 
-__device__ __forceinline__ void corr_offsets(unsigned (&off)[kDmaSlots], int wave, int lane, const TileXY &t,
-                                             int H, int W, int plane) {
+// per-lane source offsets of the 15 DMA instructions of one chunk (loader wave only)
+__device__ __forceinline__ void corr_offsets(unsigned (&off)[kDmaInstr], int lane, const TileXY &t, int H, int W, int plane) {
 #pragma unroll
-    for (int j = 0; j < kDmaSlots; ++j) {
-        const int k = wave + kND * j;
+    for (int k = 0; k < kDmaInstr; ++k) {
         int c, row, q, iy, ix;
         bool ok;
         if (k < kS2Instr) {
@@ -251,67 +251,74 @@ __device__ __forceinline__ void corr_offsets(unsigned (&off)[kDmaSlots], int wav
             const int p = (k - kS2Instr) * 64 + lane;
             c = p / (kTH * 10); row = (p / 10) % kTH; q = p % 10;
             iy = t.y0 + row; ix = t.x0 + 4 * q;
-            ok = (k < kDmaInstr) && (q < kTG);
+            ok = (q < kTG);
         }
         ok = ok && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);     // W % 4 == 0: a piece is all-in or all-out
-        off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOBv;
+        off[k] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOBv;
     }
 }
 
-__device__ __forceinline__ void corr_issue(const float *p1, const float *p2, int c0, int C, int plane, int wave,
-                                           float *buf, const unsigned (&off)[kDmaSlots]) {
+__device__ __forceinline__ void corr_issue(const float *p1, const float *p2, int c0, int C, int plane, float *buf,
+                                           const unsigned (&off)[kDmaInstr]) {
     const int nbytes = min(kCKd, C - c0) * plane * 4;
     const pwc::v4i32 r2 = pwc::make_rsrc(p2 + (int64_t)c0 * plane, nbytes);
     const pwc::v4i32 r1 = pwc::make_rsrc(p1 + (int64_t)c0 * plane, nbytes);
     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
 #pragma unroll
-    for (int j = 0; j < kDmaSlots; ++j) {
-        const int k = wave + kND * j;                       // wave-uniform instruction index, 0..17
-        if (k < kS2Instr) {
-            pwc::dma_b128(r2, base + k * 1024, off[j]);
-        } else {                                            // in1 pieces, or an all-OOB dummy (k >= kDmaInstr)
-            pwc::dma_b128(r1, base + k * 1024, off[j]);
-        }
-    }
+    for (int k = 0; k < kS2Instr; ++k) pwc::dma_b128(r2, base + k * 1024, off[k]);
+#pragma unroll
+    for (int k = kS2Instr; k < kDmaInstr; ++k) pwc::dma_b128(r1, base + k * 1024, off[k]);
 }
 
-__global__ void __launch_bounds__(kThreads, 5)
+__global__ void __launch_bounds__(kThreadsDma)
 corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, float *__restrict__ out,
                   int C, int H, int W, int tiles_x, int tiles_y, int nblk,
                   int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky) {
     __shared__ __attribute__((aligned(16))) float smem[kRing * kBufFloats];
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // dyi = dy + 4
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..8: dyi = dy + 4;  9: loader
     const int lane = tid & 63;
-    int r, g;
-    lane_to_rg(lane, r, g);
     const int plane = H * W;
     const int nchunks = (C + kCKd - 1) / kCKd;
     const int stride = gridDim.x;
     const int my_tiles = (nblk - (int)blockIdx.x + stride - 1) / stride;      // tiles blockIdx.x, +stride, ...
     const int nsteps = my_tiles * nchunks;
 
-    // ---- issue side (runs up to kRing-1 steps ahead of the compute side) -----------------------------
-    int is_tile = blockIdx.x, is_chunk = 0, is_step = 0;
-    unsigned off[kDmaSlots];
-    const float *ip1 = nullptr, *ip2 = nullptr;
-    auto issue_next = [&]() {
-        if (is_step >= nsteps) return;
-        if (is_chunk == 0) {
-            const TileXY t = tile_of(is_tile, nblk, tiles_x, tiles_y);
-            corr_offsets(off, wave, lane, t, H, W, plane);
-            ip1 = in1 + (int64_t)t.b * bs1;
-            ip2 = in2 + (int64_t)t.b * bs2;
-        }
-        corr_issue(ip1, ip2, is_chunk * kCKd, C, plane, wave, smem + (is_step % kRing) * kBufFloats, off);
-        ++is_step;
-        if (++is_chunk == nchunks) { is_chunk = 0; is_tile += stride; }
-    };
+    if (wave == kLoaderWave) {
+        // ================= producer: keeps two chunks in flight ahead of the consumers =====================
+        int is_tile = blockIdx.x, is_chunk = 0, is_step = 0;
+        unsigned off[kDmaInstr];
+        const float *ip1 = nullptr, *ip2 = nullptr;
+        auto issue_next = [&]() {
+            if (is_step >= nsteps) return;
+            if (is_chunk == 0) {
+                const TileXY t = tile_of(is_tile, nblk, tiles_x, tiles_y);
+                corr_offsets(off, lane, t, H, W, plane);
+                ip1 = in1 + (int64_t)t.b * bs1;
+                ip2 = in2 + (int64_t)t.b * bs2;
+            }
+            corr_issue(ip1, ip2, is_chunk * kCKd, C, plane, smem + (is_step % kRing) * kBufFloats, off);
+            ++is_step;
+            if (++is_chunk == nchunks) { is_chunk = 0; is_tile += stride; }
+        };
 #pragma unroll
-    for (int k = 0; k < kRing - 1; ++k) issue_next();
+        for (int k = 0; k < kRing - 1; ++k) issue_next();
+        for (int s = 0; s < nsteps; ++s) {
+            // chunk s has landed; the chunks issued after it (up to kRing-2 of them) may stay in flight
+            const int ahead = min(kRing - 2, nsteps - 1 - s);
+            if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaInstr) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaInstr) : "memory");
+            else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // B_s: consumers may read slot s%R; they have finished slot (s-1)%R
+            issue_next();                      // chunk s+R-1 -> slot (s-1)%R
+        }
+        return;
+    }
 
-    // ---- compute side ----------------------------------------------------------------------------------
+    // ================= consumers: wave = displacement row dy, lane = 4 pixels x 9 dx ======================
+    int r, g;
+    lane_to_rg(lane, r, g);
     // pixel p even: pairs dx = (0,1)(2,3)(4,5)(6,7) + single dx 8;  p odd: pairs (1,2)(3,4)(5,6)(7,8) + single dx 0
     f32x2 acc2[kPX][4];
     float acc1[kPX];
@@ -323,13 +330,8 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
     }
     int tile = blockIdx.x, chunk = 0;
     for (int s = 0; s < nsteps; ++s) {
-        // steps s+1 .. s+ahead were issued after step s and may stay in flight
-        const int ahead = min(kRing - 2, nsteps - 1 - s);
-        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaSlots) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaSlots) : "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();       // every wave's part of step s landed; ring slot (s-1)%kRing is free
-        issue_next();                       // step s + kRing - 1
+        __builtin_amdgcn_s_barrier();          // B_s
+        asm volatile("" ::: "memory");
         const float *cur = smem + (s % kRing) * kBufFloats;
         const float *s2 = cur + (r + wave) * kPitch + 4 * g;
         const float *s1 = cur + kS2Floats + r * kPitch + 4 * g;
@@ -351,7 +353,7 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
                 acc1[p] = fmaf(a[p], (p & 1) ? ws[p] : ws[p + 8], acc1[p]);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads done before the slot can be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS reads done before the next barrier frees the slot
         if (++chunk == nchunks) {
             // ---- tile finished: scale / LeakyReLU / 16-byte stores (they drain while the next tile runs)
             const TileXY t = tile_of(tile, nblk, tiles_x, tiles_y);
@@ -495,7 +497,7 @@ int launch_corr(const void *in1, const void *in2, void *out, int B, int C, int H
         if constexpr (sizeof(T) == 4) {
             if (vec && (int64_t)H * W * kCKd * 4 < 0x7fffffffLL) {
                 const int grid = (int)((nblk < kPersistentPerCU * 256) ? nblk : kPersistentPerCU * 256);
-                hipLaunchKernelGGL(corr81_dma_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st,
+                hipLaunchKernelGGL(corr81_dma_kernel, dim3((unsigned)grid), dim3(kThreadsDma), 0, st,
                                    a, b, o, C, H, W, tiles_x, tiles_y, (int)nblk, bs1, bs2, bso, scale, slope, do_leaky);
                 return pwc::check_launch("corr81_dma_kernel");
             }
