@@ -28,44 +28,48 @@ constexpr int kCK = 4;                  // channels per chunk
 constexpr int kRing = 3;                // 72 KiB -> two workgroups per CU (a 4th slot measured slower: one WG/CU)
 constexpr int kTH = 8;
 constexpr int kTW = 128;
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;              // consumer threads (4 waves); a 5th wave runs the DMA ring
+constexpr int kBlockThreads = 320;
 constexpr int kRows = kTH + 2;
 constexpr int kPitch = kTW + 8;         // floats: cols x0-4 .. x0+131
 constexpr int kQuads = kPitch / 4;      // 34 pieces per row
 constexpr int kPieces = kCK * kRows * kQuads;                   // 1360
-constexpr int kSlots = (kPieces + kThreads - 1) / kThreads;     // 6 per thread (all waves issue 6: uniform count)
+constexpr int kSlots = (kPieces + kThreads - 1) / kThreads;     // 6 x 256 pieces per ring slot
+constexpr int kInstr = kSlots * 4;                              // 24 wave-instructions of 64 x 16 B per chunk, all by the loader
 constexpr int kBuf = kSlots * kThreads * 4;                     // 6144 floats = 24 KiB per ring slot
 constexpr int kHeadWOff = (kSlots - 1) * kThreads * 4 + 2 * 256;    // floats: wave 2's last-slot strip (5632)
 constexpr int kUpWOff = (kSlots - 1) * kThreads * 4 + 3 * 256;      // floats: wave 3's last-slot strip (5888)
 constexpr int kHeadWRow = 20;           // packed head taps per channel: {co0: 9 taps, 0, co1: 9 taps, 0}
 constexpr int kUpWRow = 32;             // nn layout [ci][co][4][4]
 constexpr unsigned kOOB = 0x80000000u;
+static_assert(kRing == 3, "the loader's counted wait assumes exactly one younger chunk in flight");
 static_assert(kPieces * 4 <= kHeadWOff, "weights strip overlaps the tile");
 
 constexpr int MODE_HEAD = 1, MODE_UPFEAT = 2;
 
+// Loader wave: start the LDS-DMA of one chunk.  Instructions 0..21 carry the tile (pieces 64*i + lane), 22 the
+// head taps, 23 the upfeat taps (their pieces would be padding).
 template <int MODE>
 __device__ __forceinline__ void issue(const float *xb, const float *hw, const float *uw, int chunk, int Cin, int plane,
-                                      int wave, float *buf, const unsigned (&off)[kSlots]) {
+                                      float *buf, const unsigned (&off)[kInstr]) {
     const int c0 = chunk * kCK;
     const int cvalid = min(kCK, Cin - c0);
     const pwc::v4i32 r = pwc::make_rsrc(xb + (int64_t)c0 * plane, cvalid * plane * 4);
-    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf)) + wave * 1024;
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
 #pragma unroll
-    for (int j = 0; j < kSlots - 1; ++j) pwc::dma_b128(r, base + j * (kThreads * 16), off[j]);
-    // last slot: waves 0,1 finish the tile; waves 2,3 (whose pieces would be padding) fetch this chunk's taps
-    const unsigned last = base + (kSlots - 1) * (kThreads * 16);
-    if (wave == 2 && (MODE & MODE_HEAD)) {
-        pwc::dma_b128(pwc::make_rsrc(hw + (int64_t)c0 * kHeadWRow, cvalid * kHeadWRow * 4), last, off[kSlots - 1]);
-    } else if (wave == 3 && (MODE & MODE_UPFEAT)) {
-        pwc::dma_b128(pwc::make_rsrc(uw + (int64_t)c0 * kUpWRow, cvalid * kUpWRow * 4), last, off[kSlots - 1]);
-    } else {
-        pwc::dma_b128(r, last, off[kSlots - 1]);
-    }
+    for (int i = 0; i < kInstr - 2; ++i) pwc::dma_b128(r, base + i * 1024, off[i]);
+    if constexpr (MODE & MODE_HEAD)
+        pwc::dma_b128(pwc::make_rsrc(hw + (int64_t)c0 * kHeadWRow, cvalid * kHeadWRow * 4), base + (kInstr - 2) * 1024, off[kInstr - 2]);
+    else
+        pwc::dma_b128(r, base + (kInstr - 2) * 1024, off[kInstr - 2]);
+    if constexpr (MODE & MODE_UPFEAT)
+        pwc::dma_b128(pwc::make_rsrc(uw + (int64_t)c0 * kUpWRow, cvalid * kUpWRow * 4), base + (kInstr - 1) * 1024, off[kInstr - 1]);
+    else
+        pwc::dma_b128(r, base + (kInstr - 1) * 1024, off[kInstr - 1]);
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kBlockThreads)
 stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x, int tiles_y, int64_t bsx,
                  // HEAD: w packed [Cin][20], y [B,2,H,W]
                  const float *__restrict__ hw, const float *__restrict__ hbias, const float *__restrict__ residual,
@@ -88,22 +92,39 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
     const int y0 = by * kTH;
     const int plane = H * W;
 
-    unsigned off[kSlots];
+    const float *xb = x + (int64_t)b * bsx;
+    const int nchunks = (Cin + kCK - 1) / kCK;
+
+    if (wave == 4) {
+        // ================= producer wave: runs the ring, two chunks ahead of the consumers ==================
+        unsigned off[kInstr];
 #pragma unroll
-    for (int j = 0; j < kSlots; ++j) {
-        const int p = j * kThreads + tid;
-        const int c = p / (kRows * kQuads);
-        const int rem = p % (kRows * kQuads);
-        const int r = rem / kQuads;
-        const int q = rem % kQuads;
-        const int iy = y0 - 1 + r;
-        const int ix = x0 - 4 + 4 * q;
-        const bool ok = (p < kPieces) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);   // W % 4 == 0
-        off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+        for (int i = 0; i < kInstr; ++i) {
+            const int p = i * 64 + lane;
+            const int c = p / (kRows * kQuads);
+            const int rem = p % (kRows * kQuads);
+            const int r = rem / kQuads;
+            const int q = rem % kQuads;
+            const int iy = y0 - 1 + r;
+            const int ix = x0 - 4 + 4 * q;
+            const bool ok = (p < kPieces) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);   // W % 4 == 0
+            off[i] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+        }
+        // the tap fetches are plain contiguous copies: lane -> 16-byte piece `lane`
+        if (MODE & MODE_HEAD) off[kInstr - 2] = (lane < kCK * kHeadWRow / 4) ? lane * 16u : kOOB;
+        if (MODE & MODE_UPFEAT) off[kInstr - 1] = (lane < kCK * kUpWRow / 4) ? lane * 16u : kOOB;
+#pragma unroll
+        for (int k = 0; k < kRing - 1; ++k)
+            if (k < nchunks) issue<MODE>(xb, hw, uw, k, Cin, plane, smem + k * kBuf, off);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInstr) : "memory");   // kRing == 3
+            else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // consumers may read slot chunk%3; they are done with (chunk-1)%3
+            if (chunk + kRing - 1 < nchunks)
+                issue<MODE>(xb, hw, uw, chunk + kRing - 1, Cin, plane, smem + ((chunk + kRing - 1) % kRing) * kBuf, off);
+        }
+        return;
     }
-    // the weight fetches of waves 2 / 3 are plain contiguous copies: lane -> 16-byte piece `lane`
-    if (wave == 2 && (MODE & MODE_HEAD)) off[kSlots - 1] = (lane < kCK * kHeadWRow / 4) ? lane * 16u : kOOB;
-    if (wave == 3 && (MODE & MODE_UPFEAT)) off[kSlots - 1] = (lane < kCK * kUpWRow / 4) ? lane * 16u : kOOB;
 
     float hacc[2][4];                   // HEAD:   [co][px]
     float uacc[2][2][8];                // UPFEAT: [co][out row parity][out col 0..7] (8 output cols for 4 input px)
@@ -117,19 +138,9 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
             for (int k = 0; k < 8; ++k) uacc[co][py][k] = 0.f;
     }
 
-    const float *xb = x + (int64_t)b * bsx;
-    const int nchunks = (Cin + kCK - 1) / kCK;
-#pragma unroll
-    for (int k = 0; k < kRing - 1; ++k)
-        if (k < nchunks) issue<MODE>(xb, hw, uw, k, Cin, plane, wave, smem + k * kBuf, off);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int ahead = min(kRing - 2, nchunks - 1 - chunk);
-        if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kSlots) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kSlots) : "memory");
-        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (chunk + kRing - 1 < nchunks)
-            issue<MODE>(xb, hw, uw, chunk + kRing - 1, Cin, plane, wave, smem + ((chunk + kRing - 1) % kRing) * kBuf, off);
+        asm volatile("" ::: "memory");
         const float *cur = smem + (chunk % kRing) * kBuf;
         // channels past Cin in the last chunk: tile AND taps were range-checked to 0, so they add exactly 0
 #pragma unroll
@@ -241,7 +252,7 @@ int launch(const float *x, int B, int Cin, int H, int W, int64_t bsx,
         if (e != hipSuccess) PWC_FAIL((int)e, "stream3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), smem, st,
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kBlockThreads), smem, st,
                        x, Cin, H, W, tiles_x, tiles_y, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky,
                        uw, ubias, uy, bsuy);
     return pwc::check_launch("stream3x3_kernel");
