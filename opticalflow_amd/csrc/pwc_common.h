@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "../../include/pwc_hip.h"
 
 namespace pwc {
@@ -32,6 +34,21 @@ template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Raise a kernel's dynamic-LDS limit once per (kernel instantiation, device).  `done` is a per-instantiation
+// static array; relaxed atomics are enough (setting the attribute twice is harmless).
+constexpr int kMaxDevices = 64;
+struct LdsAttrOnce { std::atomic<unsigned char> done[kMaxDevices]; };
+inline int ensure_lds_attr(LdsAttrOnce &state, const void *kernel, int bytes, const char *who) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { set_error("%s: hipGetDevice: %s", who, hipGetErrorString(e)); return (int)e; }
+    if (dev >= 0 && dev < kMaxDevices && state.done[dev].load(std::memory_order_relaxed)) return PWC_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute(%d B LDS): %s", who, bytes, hipGetErrorString(e)); return (int)e; }
+    if (dev >= 0 && dev < kMaxDevices) state.done[dev].store(1, std::memory_order_relaxed);
+    return PWC_OK;
+}
 
 // ---- hand-issued LDS-DMA (buffer_load ... lds) ----------------------------------------------------------
 // hipcc treats a builtin LDS-DMA as an LDS store that may alias every later ds_read and drains it with

@@ -253,14 +253,9 @@ int launch(const ConvArgs &a) {
         const int groups = (a.CoutP / 32 + MT - 1) / MT;
         if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: grid too large");
         auto kern = conv3x3_mfma_kernel<MT, NT, S, D, TWO>;
-        static bool attr_set = false;   // one per instantiation
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, G::kSmemBytes);
-            if (e != hipSuccess)
-                PWC_FAIL((int)e, "pwc_conv2d_fwd: hipFuncSetAttribute(%d B LDS): %s", G::kSmemBytes, hipGetErrorString(e));
-            attr_set = true;
-        }
+        static pwc::LdsAttrOnce attr;   // one per instantiation, tracked per device
+        if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmemBytes, "pwc_conv2d_fwd"))
+            return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
                            a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
                            tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky);

@@ -245,13 +245,8 @@ int launch(const float *x, int B, int Cin, int H, int W, int64_t bsx,
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "stream3x3: grid too large");
     constexpr int smem = kRing * kBuf * 4;      // 96 KiB
     auto kern = stream3x3_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) PWC_FAIL((int)e, "stream3x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static pwc::LdsAttrOnce attr;       // per instantiation, tracked per device
+    if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), smem, "stream3x3")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kBlockThreads), smem, st,
                        x, Cin, H, W, tiles_x, tiles_y, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky,
                        uw, ubias, uy, bsuy);

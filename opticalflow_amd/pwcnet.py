@@ -88,6 +88,7 @@ class PWCDCNet(nn.Module):
         self._plans: Dict[Tuple, PwcPlan] = {}
         self._graphs: Dict[Tuple, Tuple] = {}
         self._versions: Optional[Tuple[int, ...]] = None
+        self._param_list = None
 
     # ---- reference surface --------------------------------------------------------------------
     def warp(self, x: torch.Tensor, flo: torch.Tensor) -> torch.Tensor:
@@ -117,12 +118,17 @@ class PWCDCNet(nn.Module):
                 self.normalize_corr, self.align_corners)
 
     def _param_versions(self):
-        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+        # in-place updates bump _version; re-homing (.to/.cuda/load_state_dict) goes through _apply /
+        # load_state_dict below, which drop the plans explicitly
+        if self._param_list is None:
+            self._param_list = list(self.parameters())
+        return tuple(p._version for p in self._param_list)
 
     def invalidate_plans(self):
         self._plans.clear()
         self._graphs.clear()
         self._versions = None
+        self._param_list = None
 
     def _plan_for(self, x) -> PwcPlan:
         ver = self._param_versions()
