@@ -66,14 +66,14 @@ class PwcPlan:
 
         self.size = {l: (H >> l, W >> l) for l in range(1, 7)}
         # pyramid scratch: per level two ping-pong buffers for the 2B batch, plus c2 (second image)
-        self.pyr_a, self.pyr_b, self.c2 = {}, {}, {}
+        self.pyr_a, self.pyr_b, self.c1, self.c2 = {}, {}, {}, {}
         for l in range(1, 7):
             h, w = self.size[l]
             c = PYRAMID_CH[l]
-            self.pyr_a[l] = torch.empty((2 * B, c, h, w), **kw)
-            self.pyr_b[l] = torch.empty((2 * B, c, h, w), **kw)
-        for l in range(2, 6):
-            self.c2[l] = self.pyr_a[l][B:]        # second image's level features (dense view)
+            self.pyr_a[l] = torch.empty((self._slots(B), c, h, w), **kw)
+            self.pyr_b[l] = torch.empty((self._slots(B), c, h, w), **kw)
+        for l in range(2, 7):
+            self.c1[l], self.c2[l] = self._pair_views(self.pyr_a[l], B)
         self.warped = {l: torch.empty((B, PYRAMID_CH[l], *self.size[l]), **kw) for l in range(2, 6)}
         self.arena = {}
         for l in range(2, 7):
@@ -89,6 +89,15 @@ class PwcPlan:
             for key, t in params.items():
                 if key.endswith(".weight") and t.dim() == 4 and t.shape[2:] == (3, 3):
                     self.packed[key[:-len(".weight")]] = ops.pack_conv3x3(t)
+
+    @staticmethod
+    def _slots(B: int) -> int:
+        return 2 * B
+
+    @staticmethod
+    def _pair_views(buf: torch.Tensor, B: int):
+        """first / second image's level features as dense views of the pyramid buffer"""
+        return buf[:B], buf[B:]
 
     # ---- layer primitives -----------------------------------------------------------------------
     def _conv(self, name: str, x: torch.Tensor, out: torch.Tensor, stride: int = 1, dilation: int = 1,
@@ -121,37 +130,42 @@ class PwcPlan:
             raise ValueError("plan built for %s %s on %s, got %s %s on %s" % (
                 (B, 6, self.H, self.W), self.dtype, self.device, tuple(x.shape), x.dtype, x.device))
         x = ops.densify(x)
-        nd = self.nd
-        base = DENSE_TOTAL                      # first channel after the dense-block outputs
         # -- feature pyramid, both images as one 2B batch (PWCNet.py:184-195) ----------------------
+        self._pyramid([(x[:, :3], 0, B), (x[:, 3:], B, 2 * B)], 0, 2 * B)
+        return self._decode()
+
+    def _pyramid(self, images, lo: int, hi: int) -> None:
+        """conv1a..conv6b over the batch slots [lo,hi) of the pyramid buffers; `images` lists
+        (rgb [n,3,H,W], slot_lo, slot_hi) sources for the first conv."""
         prev = None
         for l in range(1, 7):
             na, naa, nb = PYRAMID_NAMES[l - 1]
-            a, bb = self.pyr_a[l], self.pyr_b[l]
+            a, bb = self.pyr_a[l][lo:hi], self.pyr_b[l][lo:hi]
             if l == 1:
-                self._conv(na, x[:, :3], a[:B], stride=2)
-                self._conv(na, x[:, 3:], a[B:], stride=2)
+                for img, s0, s1 in images:
+                    self._conv(na, img, self.pyr_a[1][s0:s1], stride=2)
             else:
                 self._conv(na, prev, a, stride=2)
             self._conv(naa, a, bb)
             self._conv(nb, bb, a)
-            if 2 <= l <= 5:
-                # level features: first image into the level's arena slot; c2 is the view a[B:]
-                # (the next level still reads the dense 2B batch in `a`)
-                c = PYRAMID_CH[l]
-                off = base + nd
-                self.arena[l][:, off:off + c].copy_(a[:B])
             prev = a
-        # -- coarse-to-fine decoder (PWCNet.py:198-265) ---------------------------------------------
+
+    def _decode(self) -> torch.Tensor:
+        """Coarse-to-fine decoder + context network over self.c1[l] / self.c2[l] (PWCNet.py:198-268)."""
+        nd = self.nd
+        base = DENSE_TOTAL                      # first channel after the dense-block outputs
         for l in (6, 5, 4, 3, 2):
             ar = self.arena[l]
             c = PYRAMID_CH[l]
             corr_slot = ar[:, base:base + nd]
             if l == 6:
-                ops.correlation(self.pyr_a[6][:B], self.pyr_a[6][B:], self.md, 1, self.md, 1, 1, 1.0,
+                ops.correlation(self.c1[6], self.c2[6], self.md, 1, self.md, 1, 1, 1.0,
                                 normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
             else:
                 off = base + nd
+                # first image's level features go into the level's arena slot (they are part of the
+                # dense block's input, PWCNet.py:215); c2 is only ever read by the warp
+                ar[:, off:off + c].copy_(self.c1[l])
                 up_flow = ar[:, off + c:off + c + 2]
                 ops.warp(self.c2[l], up_flow, flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
                          out=self.warped[l])
@@ -196,3 +210,57 @@ class PwcPlan:
         tot += sum(t.numel() * t.element_size() for t in self.ctx + [self.flow_out])
         tot += sum(t.numel() * t.element_size() for t in self.packed.values())
         return tot
+
+
+class PwcVideoPlan(PwcPlan):
+    """Plan for consecutive frame pairs (f[t], f[t+1]) of one video, the loop of
+    ``pwc_extract_flow_video.py:262-305`` (``frame1 = frame2`` each iteration).
+
+    The reference runs the feature pyramid on both frames of every pair, i.e. twice per frame.  Here each
+    level's pyramid buffer has B+1 batch slots: slot 0 carries the last frame of the previous step, slots
+    1..B receive the pyramid of the B new frames, and the decoder's first/second-image features are the
+    overlapping views [0:B] / [1:B+1] of the same buffer -- no copy, one pyramid pass per frame.
+    """
+
+    def __init__(self, params, B, H, W, device, dtype=torch.float32, md=4, normalize_corr=False,
+                 align_corners=False, conv_backend="hip"):
+        super().__init__(params, B, H, W, device, dtype, md, normalize_corr, align_corners, conv_backend)
+        self.primed = False
+
+    @staticmethod
+    def _slots(B: int) -> int:
+        return B + 1
+
+    @staticmethod
+    def _pair_views(buf: torch.Tensor, B: int):
+        return buf[:B], buf[1:]
+
+    def _check(self, frames: torch.Tensor, n: int) -> torch.Tensor:
+        if tuple(frames.shape) != (n, 3, self.H, self.W) or frames.dtype != self.dtype or frames.device != self.device:
+            raise ValueError("expected frames %s %s on %s, got %s %s on %s" % (
+                (n, 3, self.H, self.W), self.dtype, self.device, tuple(frames.shape), frames.dtype, frames.device))
+        return ops.densify(frames)
+
+    def _carry(self) -> None:
+        for l in range(2, 7):
+            self.pyr_a[l][0].copy_(self.pyr_a[l][self.B])
+
+    def prime(self, frame: torch.Tensor) -> None:
+        """Pyramid of the very first frame [1,3,H,W] -> carry slot."""
+        f = self._check(frame, 1)
+        self._pyramid([(f, self.B, self.B + 1)], self.B, self.B + 1)
+        self._carry()
+        self.primed = True
+
+    def push(self, frames: torch.Tensor) -> torch.Tensor:
+        """B new frames [B,3,H,W] -> flows of the pairs (previous, frames[0]), (frames[0], frames[1]), ..."""
+        if not self.primed:
+            raise RuntimeError("PwcVideoPlan.push before prime(first_frame)")
+        f = self._check(frames, self.B)
+        self._pyramid([(f, 1, self.B + 1)], 1, self.B + 1)
+        out = self._decode()
+        self._carry()
+        return out
+
+    def run(self, x):
+        raise RuntimeError("PwcVideoPlan is driven by prime()/push(), not run()")

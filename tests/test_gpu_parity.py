@@ -123,6 +123,30 @@ def test_correlation_module_and_pybind_shim(dev):
     assert torch.allclose(a2.grad.cpu(), ar.grad, rtol=1e-4, atol=1e-4)
 
 
+def test_corr_and_warp_fp16_storage(dev):
+    """PWC_F16 tensors (fp32 accumulation inside): compare with the oracle on the SAME fp16-rounded inputs.
+    Tolerance = half-precision rounding of the result (2^-10 relative) + accumulation noise."""
+    from opticalflow_amd import ops
+    for shp in ((2, 32, 24, 64), (1, 7, 13, 11)):                      # vector path / scalar path
+        a = seeded_rand(shp, 120, -1, 1).half()
+        b = seeded_rand(shp, 121, -1, 1).half()
+        ref = O.correlation(a.float(), b.float(), 4, 1, 4, 1, 1, 1)
+        got = ops.correlation(a.to(dev), b.to(dev)).float().cpu()
+        assert got.dtype == torch.float32 and ops.correlation(a.to(dev), b.to(dev)).dtype == torch.float16
+        assert (got - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+        gotn = ops.correlation(a.to(dev), b.to(dev), normalize=True, leaky_slope=0.1).float().cpu()
+        assert (gotn - O.leaky_relu(ref / shp[1])).abs().max().item() <= 2e-3
+    x = seeded_rand((2, 9, 14, 32), 122, -1, 1).half()
+    flo = seeded_rand((2, 2, 14, 32), 123, -3, 3).half()
+    ref = O.warp(x.float(), flo.float() * 1.25)
+    got = ops.warp(x.to(dev), flo.to(dev), flow_scale=1.25).float().cpu()
+    # coordinates are fp32 in the kernel; values are rounded to half on store
+    assert ((got == 0) == (ref == 0)).float().mean().item() > 0.995
+    assert (got - ref).abs().max().item() < 2e-3
+    with pytest.raises(TypeError):
+        ops.correlation(a.double().to(dev), b.double().to(dev))
+
+
 # ------------------------------------------------------------------ warp
 def test_warp_golden(dev):
     from opticalflow_amd import ops
