@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 1
+#define PWC_ABI_VERSION 2
 
 /* element types */
 #define PWC_F32 0
@@ -90,12 +90,20 @@ int pwc_conv3x3_pack(const void *w, void *wp, int Cin, int Cout, int dtype, void
 
 /* 3x3 convolution, padding == dilation (so H,W are preserved at stride 1; Hout = (H-1)/stride+1),
  * + bias, optional LeakyReLU and residual.  x:[B,Cin,H,W], y:[B,Cout,Hout,Wout],
- * wp = output of pwc_conv3x3_pack, bias:[Cout] f32, residual: same geometry as y or NULL. */
+ * wp = output of pwc_conv3x3_pack, bias:[Cout] f32, residual: same geometry as y or NULL.
+ * workspace (device, 4-byte aligned, may be NULL): scratch for the split-K route taken by layers with few
+ * output tiles and many input channels (pyramid levels 6-4, batch-1 inference): partial sums per Cin range,
+ * then a fixed-order reduction (deterministic).  A layer whose pwc_conv2d_workspace_bytes() exceeds
+ * workspace_bytes runs unsplit -- same result up to fp32 summation order.  One workspace may be shared by all
+ * layers launched on the same stream. */
 int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, const void *residual, void *y,
                    int B, int Cin, int H, int W, int Cout,
                    int stride, int dilation, int dtype, unsigned flags, float leaky_slope,
                    int64_t x_bstride, int64_t y_bstride, int64_t res_bstride,
+                   void *workspace, int64_t workspace_bytes,
                    void *stream);
+/* Bytes of workspace the split-K route of this layer needs (0: the layer never splits; <0: bad shape). */
+int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation);
 
 /* ConvTranspose2d(kernel 4, stride 2, padding 1) + bias.  x:[B,Cin,H,W], w:[Cin,Cout,4,4] (nn layout),
  * y:[B,Cout,2H,2W]. */

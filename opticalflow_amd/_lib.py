@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
@@ -33,7 +33,8 @@ SIGNATURES = {
     "pwc_conv3x3_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pwc_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
-                               c_int64, c_int64, c_int64, c_void_p]),
+                               c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "pwc_conv2d_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "pwc_deconv4x4s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_head_upfeat_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

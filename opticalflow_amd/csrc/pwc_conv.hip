@@ -60,7 +60,35 @@ pack3x3_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cin, int
     wp[i] = v;
 }
 
+// y = act(bias + sum_z partial[z]) (+ residual): fixed z order, one thread per output element
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias, const float *__restrict__ residual,
+                     float *__restrict__ y, int Cout, int oplane, int ksplit, int64_t per_image, int64_t total,
+                     int64_t bsy, int64_t bsr, float slope, int do_leaky) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / per_image;
+    const int64_t r = i - b * per_image;                 // co*oplane + pixel
+    float v = bias[(int)(r / oplane)];
+    for (int z = 0; z < ksplit; ++z) v += partial[(int64_t)z * total + i];
+    if (do_leaky) v = pwc::leaky(v, slope);
+    if (residual) v += residual[b * bsr + r];
+    y[b * bsy + r] = v;
+}
+
+// does this layer take the split-K route?  (stride 1, dilation 1 only)
+inline pwc_conv::SplitPlan split_for(int B, int Cin, int H, int W, int Cout, int stride, int dilation) {
+    if (stride != 1 || dilation != 1) return {1, 0};
+    return pwc_conv::plan_split(B, Cin, H, W, cout_padded(Cout));
+}
+
 }  // namespace
+
+extern "C" int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation) {
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return -1;
+    const pwc_conv::SplitPlan sp = split_for(B, Cin, H, W, Cout, stride, dilation);
+    return sp.ksplit > 1 ? (int64_t)sp.ksplit * B * Cout * H * W * (int64_t)sizeof(float) : 0;
+}
 
 extern "C" int64_t pwc_conv3x3_packed_bytes(int Cin, int Cout, int dtype) {
     if (Cin <= 0 || Cout <= 0 || dtype != PWC_F32) return -1;
@@ -83,7 +111,8 @@ extern "C" int pwc_conv3x3_pack(const void *w, void *wp, int Cin, int Cout, int 
 extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, const void *residual, void *y,
                               int B, int Cin, int H, int W, int Cout,
                               int stride, int dilation, int dtype, unsigned flags, float leaky_slope,
-                              int64_t x_bstride, int64_t y_bstride, int64_t res_bstride, void *stream) {
+                              int64_t x_bstride, int64_t y_bstride, int64_t res_bstride,
+                              void *workspace, int64_t workspace_bytes, void *stream) {
     if (!x || !wp || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: null pointer");
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: bad shape");
     if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_fwd: dtype %d", dtype);
@@ -107,7 +136,13 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
     a.slope = leaky_slope;
     a.do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
     a.stream = static_cast<hipStream_t>(stream);
-    if (Cout == 2 && stride == 1 && dilation == 1) {
+    // split-K: few output tiles and a long Cin -> partial sums over Cin ranges into the caller's workspace, then
+    // a fixed-order reduction.  Without a (large enough) workspace the layer runs unsplit.
+    const pwc_conv::SplitPlan sp = split_for(B, Cin, H, W, Cout, stride, dilation);
+    const bool split = sp.ksplit > 1 && workspace &&
+                       workspace_bytes >= (int64_t)sp.ksplit * B * Cout * plane * (int64_t)sizeof(float) &&
+                       !(reinterpret_cast<uintptr_t>(workspace) & 3u);
+    if (Cout == 2 && stride == 1 && dilation == 1 && !(split && !pwc_conv::stream3x3_ok(B, Cin, H, W, a.x, a.bsx))) {
         // 2-channel heads: stream the arena through the LDS ring when the image is wide enough, split Cin over
         // waves when the level is tiny; in between the MFMA kernel (MT=1) is still the fastest
         const float *w_raw = a.wp + mfma_image_floats(Cin, Cout);
@@ -119,6 +154,17 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
             rc = pwc_conv::run_head(a.x, w_raw, a.bias, a.residual, a.y, B, Cin, H, W, Cout, a.bsx, a.bsy, a.bsr,
                                     a.slope, a.do_leaky, a.stream);
         if (rc != PWC_EUNSUPPORTED) return rc;
+    }
+    if (split) {
+        a.partial = static_cast<float *>(workspace);
+        a.ksplit = sp.ksplit;
+        a.cps = sp.cps;
+        if (const int rc = pwc_conv::run_s1d1(a)) return rc;
+        const int64_t per_image = (int64_t)Cout * plane, total = per_image * B;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a.stream,
+                           a.partial, a.bias, a.residual, a.y, Cout, (int)plane, sp.ksplit, per_image, total,
+                           a.bsy, a.bsr, a.slope, a.do_leaky);
+        return pwc::check_launch("splitk_reduce_kernel");
     }
     if (stride == 1) {
         switch (dilation) {

@@ -78,7 +78,7 @@ namespace {   // kernels and launchers have internal linkage: each translation u
 template <class G>
 __device__ __forceinline__ void issue_chunk(const float *xb, const float *wg, int chunk, int Cin, int plane,
                                             int64_t wchunk, unsigned wbytes, int wave, float *buf,
-                                            const unsigned (&in_off)[G::kInSlots], const unsigned (&w_off)[G::kWSlots]) {
+                                            const unsigned *in_off, const unsigned *w_off) {
     const int c0 = chunk * G::kCK;
     const int cvalid = min(G::kCK, Cin - c0);
     // descriptors built from readfirstlane'd words so hipcc can prove them wave-uniform
@@ -97,12 +97,16 @@ __device__ __forceinline__ void issue_chunk(const float *xb, const float *wg, in
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void *)(dst_w + j * kThreads * 4), 16, w_off[j], 0, 0, 0);
 }
 
-template <int MT, int NT, int S, int D, int TWO>
+// SPLIT=1 (split-K): blockIdx.z owns the chunk range [z*cps, (z+1)*cps) and writes its raw partial sums to
+// y = workspace [z][b][Cout][Ho][Wo] (bsy = Cout*Ho*Wo, zstride = B*bsy); bias / activation / residual are applied by
+// splitk_reduce_kernel, which adds the partials in fixed z order (deterministic).  Used when a layer has too
+// few output tiles to occupy 256 CUs and a long Cin (levels 6-4, batch-1 inference).
+template <int MT, int NT, int S, int D, int TWO, int SPLIT>
 __global__ void __launch_bounds__(kThreads, (TWO ? 2 : 1))
 conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                     const float *__restrict__ residual, float *__restrict__ y,
                     int Cin, int H, int W, int Cout, int CoutP, int Ho, int Wo, int tiles_x, int tiles_y,
-                    int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky) {
+                    int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky, int cps, int64_t zstride) {
     using G = Geom<MT, NT, S, D, TWO>;
     constexpr int CK = G::kCK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -158,7 +162,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-            const float bv = bias[min(co, Cout - 1)];          // rows >= Cout are never stored
+            const float bv = SPLIT ? 0.f : bias[min(co, Cout - 1)];          // rows >= Cout are never stored
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt][j] = bv;
         }
@@ -170,15 +174,20 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     const float *wg = wp + g * G::kCoutT;                       // this workgroup's cout columns
     const unsigned wbytes = (unsigned)(wchunk - g * G::kCoutT) * 4u;
 
-    issue_chunk<G>(xb, wg, 0, Cin, plane, wchunk, wbytes, wave, smem, in_off, w_off);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    int chunk_lo = 0, chunk_hi = nchunks;
+    if constexpr (SPLIT) {
+        chunk_lo = (int)blockIdx.z * cps;                       // host guarantees chunk_lo < nchunks
+        chunk_hi = min(nchunks, chunk_lo + cps);
+    }
+    issue_chunk<G>(xb, wg, chunk_lo, Cin, plane, wchunk, wbytes, wave, smem + (chunk_lo & 1) * G::kBufFloats, in_off, w_off);
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         float *cur = smem + (chunk & 1) * G::kBufFloats;
         // This wave's DMA of `chunk` has landed (explicit wait: hipcc does not reliably keep its own
         // vmcnt(0) in front of the in-loop barrier for LDS-DMA), then the barrier makes every wave's
         // part visible and guarantees the other buffer is no longer being read.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (chunk + 1 < nchunks)
+        if (chunk + 1 < chunk_hi)
             issue_chunk<G>(xb, wg, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
                            in_off, w_off);
 
@@ -218,10 +227,14 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
                 const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
                 if (co >= Cout) continue;
                 float v = acc[mt][nt][j];
-                if (do_leaky) v = leaky(v, slope);
                 const int64_t off = (int64_t)co * oplane + (int64_t)oy * Wo + ox;
-                if (residual) v += residual[(int64_t)b * bsr + off];
-                y[(int64_t)b * bsy + off] = v;
+                if constexpr (SPLIT) {
+                    y[(int64_t)blockIdx.z * zstride + (int64_t)b * bsy + off] = v;
+                } else {
+                    if (do_leaky) v = leaky(v, slope);
+                    if (residual) v += residual[(int64_t)b * bsr + off];
+                    y[(int64_t)b * bsy + off] = v;
+                }
             }
         }
     }
@@ -237,7 +250,30 @@ struct ConvArgs {
     float slope;
     int do_leaky;
     hipStream_t stream;
+    // split-K (set by pwc_conv2d_fwd when a workspace is supplied and the layer qualifies): partial sums go to
+    // `partial` [ksplit][B][Cout][Ho][Wo], `cps` chunks of 8 input channels per split
+    float *partial = nullptr;
+    int ksplit = 1, cps = 0;
 };
+
+// Split-K plan shared by pwc_conv2d_fwd and pwc_conv2d_workspace_bytes: ksplit (1 = do not split) and the
+// 8-channel chunks per split, for a stride-1 dilation-1 layer run with the 4x32-pixel x 32-cout tile.
+struct SplitPlan { int ksplit, cps; };
+inline SplitPlan plan_split(int B, int Cin, int Ho, int Wo, int CoutP) {
+    static const int knob = [] { const char *e = getenv("PWC_CONV_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
+    const int64_t blocks = (int64_t)B * ((Wo + kTileW - 1) / kTileW) * ((Ho + 3) / 4) * (CoutP / 32);
+    const int nchunks = (Cin + 7) / 8;
+    // measured (tools/sweep_split.sh): a short K only pays when the grid is nearly empty
+    if (knob == 0 || blocks > 256 || nchunks < (blocks <= 64 ? 8 : 16)) return {1, nchunks};
+    // aim at ~512 workgroups (two per CU) but keep at least 3 chunks per split
+    int ks = (int)((512 + blocks - 1) / blocks);
+    if (knob > 0) ks = knob;
+    ks = min(ks, nchunks / 3);
+    if (ks < 2) return {1, nchunks};
+    const int cps = (nchunks + ks - 1) / ks;
+    ks = (nchunks + cps - 1) / cps;                     // no empty split
+    return {ks, cps};
+}
 
 namespace {
 
@@ -252,15 +288,34 @@ int launch(const ConvArgs &a) {
         const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
         const int groups = (a.CoutP / 32 + MT - 1) / MT;
         if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: grid too large");
-        auto kern = conv3x3_mfma_kernel<MT, NT, S, D, TWO>;
+        auto kern = conv3x3_mfma_kernel<MT, NT, S, D, TWO, 0>;
         static pwc::LdsAttrOnce attr;   // one per instantiation, tracked per device
         if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmemBytes, "pwc_conv2d_fwd"))
             return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
                            a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
-                           tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky);
+                           tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky, 0, (int64_t)0);
         return pwc::check_launch("conv3x3_mfma_kernel");
     }
+}
+
+// split-K launch of the 4x32 x 32-cout tile (CK = 8): raw partials into a.partial
+template <int S, int D>
+int launch_split(const ConvArgs &a) {
+    using G = Geom<1, 1, S, D, 0>;
+    const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+    const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
+    const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
+    const int groups = a.CoutP / 32;
+    auto kern = conv3x3_mfma_kernel<1, 1, S, D, 0, 1>;
+    static pwc::LdsAttrOnce attr;
+    if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmemBytes, "pwc_conv2d_fwd"))
+        return rc;
+    const int64_t bsp = (int64_t)a.Cout * a.Ho * a.Wo;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups, (unsigned)a.ksplit), dim3(kThreads), G::kSmemBytes,
+                       a.stream, a.x, a.wp, a.bias, (const float *)nullptr, a.partial, a.Cin, a.H, a.W, a.Cout, a.CoutP,
+                       a.Ho, a.Wo, tiles_x, tiles_y, a.bsx, bsp, (int64_t)0, 0.f, 0, a.cps, (int64_t)a.B * bsp);
+    return pwc::check_launch("conv3x3_mfma_kernel<split>");
 }
 
 // (MT, NT, TWO) choice by a cost model fitted to measurements on MI355X (time in units of one MFMA

@@ -85,10 +85,21 @@ class PwcPlan:
         self.ctx = [torch.empty((B, c, h2, w2), **kw) for c, _ in CONTEXT]
 
         self.packed: Dict[str, torch.Tensor] = {}
+        self.workspace: Optional[torch.Tensor] = None
         if conv_backend == "hip":
             for key, t in params.items():
                 if key.endswith(".weight") and t.dim() == 4 and t.shape[2:] == (3, 3):
                     self.packed[key[:-len(".weight")]] = ops.pack_conv3x3(t)
+            # one split-K scratch shared by every stride-1 conv of the decoder (they run back to back on one stream)
+            need = 0
+            for l in range(2, 7):
+                h, w = self.size[l]
+                cin = level_in_channels(l, self.nd)
+                for co in DENSE_OUT + (2,):
+                    need = max(need, ops.conv3x3_workspace_bytes(B, cin, h, w, co))
+                    cin += co if co != 2 else 0
+            if need:
+                self.workspace = torch.empty((need // 4,), **kw)
 
     @staticmethod
     def _slots(B: int) -> int:
@@ -106,7 +117,7 @@ class PwcPlan:
         w, b = self.p[key + ".weight"], self.p[key + ".bias"]
         if self.conv_backend == "hip":
             ops.conv3x3(x, self.packed[key], b, w.shape[0], stride=stride, dilation=dilation,
-                        leaky_slope=LEAKY if act else None, residual=residual, out=out)
+                        leaky_slope=LEAKY if act else None, residual=residual, out=out, workspace=self.workspace)
         else:
             # BASELINE config[1]: convolutions by PyTorch-ROCm (MIOpen); correlation/warp stay HIP.
             y = F.conv2d(x, w, b, stride=stride, padding=dilation, dilation=dilation)

@@ -159,7 +159,9 @@ def pack_conv3x3(weight: torch.Tensor) -> torch.Tensor:
 
 def conv3x3(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cout: int, stride: int = 1,
             dilation: int = 1, leaky_slope: Optional[float] = 0.1, residual: Optional[torch.Tensor] = None,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`workspace`: optional device scratch (any dtype, see conv3x3_workspace_bytes) enabling the split-K
+    route for layers with few output tiles; without it the layer runs unsplit."""
     lib = _lib.load()
     bsx = _plane_dense(x, "x")
     B, cin, H, W = x.shape
@@ -182,12 +184,25 @@ def conv3x3(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cout: in
         bsr = _plane_dense(residual, "residual")
         res_ptr = residual.data_ptr()
         flags |= FLAG_CONV_RESIDUAL
+    ws_ptr, ws_bytes = 0, 0
+    if workspace is not None:
+        if workspace.device != x.device or not workspace.is_contiguous():
+            raise ValueError("workspace must be a contiguous tensor on %s" % x.device)
+        ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     with torch.cuda.device(x.device):
         rc = lib.pwc_conv2d_fwd(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr(), res_ptr, out.data_ptr(),
                                 B, cin, H, W, cout, stride, dilation, _dtype_code(x), flags,
-                                float(leaky_slope or 0.0), bsx, bsy, bsr, _stream(x))
+                                float(leaky_slope or 0.0), bsx, bsy, bsr, ws_ptr, ws_bytes, _stream(x))
     check(rc, "pwc_conv2d_fwd")
     return out
+
+
+def conv3x3_workspace_bytes(B: int, cin: int, H: int, W: int, cout: int, stride: int = 1, dilation: int = 1) -> int:
+    """Scratch bytes the split-K route of this layer wants (0 = it never splits)."""
+    n = _lib.load().pwc_conv2d_workspace_bytes(B, cin, H, W, cout, stride, dilation)
+    if n < 0:
+        raise ValueError("bad conv geometry")
+    return int(n)
 
 
 def head_upfeat_supported(B: int, H: int, W: int) -> bool:

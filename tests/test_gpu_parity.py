@@ -221,6 +221,42 @@ def test_conv3x3_vs_torch_cpu(dev, case):
     assert err <= 3e-6 * (cin * 9) ** 0.5, (case, err)
 
 
+@pytest.mark.parametrize("case", [(1, 529, 128, 7, 16, True), (2, 565, 32, 14, 32, True), (1, 1010, 2, 14, 32, False),
+                                  (3, 213, 96, 9, 33, True), (16, 661, 64, 7, 16, True)])
+def test_conv3x3_split_k_route(dev, case):
+    """Layers with few output tiles and a long Cin go through the split-K kernel + fixed-order reduction when a
+    workspace is supplied (pwc_conv2d_workspace_bytes > 0): same result as torch fp64 within fp32 rounding, equal
+    (to summation order) to the unsplit route, bit-identical run to run, arena slices / residual honoured."""
+    from opticalflow_amd import ops
+    B, cin, cout, H, W, act = case
+    need = ops.conv3x3_workspace_bytes(B, cin, H, W, cout)
+    assert need > 0, "case is meant to qualify for split-K"
+    assert ops.conv3x3_workspace_bytes(16, 565, 112, 256, 128) == 0        # the big level-2 layers never split
+    x = seeded_rand((B, cin, H, W), 160, -1, 1)
+    w = seeded_rand((cout, cin, 3, 3), 161, -1, 1) * (2.0 / (cin * 9)) ** 0.5
+    bias = seeded_rand((cout,), 162, -0.5, 0.5)
+    res = seeded_rand((B, cout, H, W), 163, -1, 1)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    if act:
+        ref = F.leaky_relu(ref, 0.1)
+    ref = ref + res.double()
+    ws = torch.empty((need // 4,), device=dev)
+    wp = ops.pack_conv3x3(w.to(dev))
+    arena = torch.full((B, cout + 5, H, W), 7.0, device=dev)                 # output is a channel slice
+    kw = dict(leaky_slope=0.1 if act else None, residual=res.to(dev))
+    ops.conv3x3(x.to(dev), wp, bias.to(dev), cout, out=arena[:, 3:3 + cout], workspace=ws, **kw)
+    got = arena[:, 3:3 + cout].cpu()
+    assert (arena[:, :3] == 7).all() and (arena[:, 3 + cout:] == 7).all()
+    tol = 3e-6 * (cin * 9) ** 0.5
+    assert (got.double() - ref).abs().max().item() <= tol
+    unsplit = ops.conv3x3(x.to(dev), wp, bias.to(dev), cout, **kw).cpu()
+    assert (got - unsplit).abs().max().item() <= tol
+    again = ops.conv3x3(x.to(dev), wp, bias.to(dev), cout, workspace=ws, **kw).cpu()
+    assert torch.equal(again, got)
+    small = ops.conv3x3(x.to(dev), wp, bias.to(dev), cout, workspace=ws[:16], **kw).cpu()   # too small -> unsplit
+    assert torch.equal(small, unsplit)
+
+
 def test_conv3x3_arena_slices_residual_no_act(dev):
     from opticalflow_amd import ops
     B, H, W = 2, 16, 32

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Micro-bench of single conv layers at the BASELINE level-2 geometry (B=16, 112x256) with HIP events."""
+"""Micro-bench of single conv layers with HIP events.  Default geometry: BASELINE level 2 (B=16, 112x256);
+PWC_BENCH_GEOM="B,H,W" overrides it; PWC_BENCH_WS=1 supplies a split-K workspace (then PWC_CONV_SPLIT=k forces k)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from opticalflow_amd import ops
 dev = torch.device('cuda:0')
-B, H, W = 16, 112, 256
+B, H, W = [int(v) for v in os.environ.get("PWC_BENCH_GEOM", "16,112,256").split(",")]
 cases = [("dc_conv1", 565, 128, 1), ("conv2_0", 117, 128, 1), ("conv2_2", 373, 96, 1), ("conv2_3", 469, 64, 1),
          ("conv2_4", 533, 32, 1), ("dc_conv2", 128, 128, 2), ("dc_conv4", 128, 96, 8), ("dc_conv5", 96, 64, 16)]
 if len(sys.argv) > 1:
@@ -25,6 +26,10 @@ for name, cin, cout, dil in cases:
     b = torch.zeros(cout, device=dev)
     wp = ops.pack_conv3x3(w)
     y = torch.empty(B, cout, H, W, device=dev)
-    ms = t(lambda: ops.conv3x3(x, wp, b, cout, dilation=dil, out=y))
+    ws = None
+    if os.environ.get("PWC_BENCH_WS") == "1":
+        need = ops.conv3x3_workspace_bytes(B, cin, H, W, cout, 1, dil)
+        ws = torch.empty((max(need, 4) // 4,), device=dev)
+    ms = t(lambda: ops.conv3x3(x, wp, b, cout, dilation=dil, out=y, workspace=ws), reps=30)
     fl = 2.0 * cout * cin * 9 * H * W * B
     print("%-9s %4d->%3d d%-2d  %8.1f us  %6.1f TFLOP/s (%.1f%% of 157.3)" % (name, cin, cout, dil, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 1.573))

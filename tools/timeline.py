@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per-launch timeline of ONE forward of bench.py.
 
-usage: tools/timeline.py <kernel_trace.csv> [--full]
+usage: tools/timeline.py <kernel_trace.csv> [--full] [--min-grid=N]
 A forward starts at the two back-to-back stride-2 launches of conv1a on the two images.
 """
 import csv
@@ -21,11 +21,15 @@ def short(n):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
+    min_grid = 256 * 1000
+    for a in sys.argv[2:]:
+        if a.startswith("--min-grid="):
+            min_grid = int(a.split("=")[1])
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
     starts = [i for i in range(len(rows) - 1)
               if ("S2,D1" in names[i]) and names[i + 1] == names[i]
-              and rows[i]["Grid_Size_X"] == rows[i + 1]["Grid_Size_X"] and int(rows[i]["Grid_Size_X"]) > 256 * 1000]
+              and rows[i]["Grid_Size_X"] == rows[i + 1]["Grid_Size_X"] and int(rows[i]["Grid_Size_X"]) > min_grid]
     if len(starts) < 3:
         print("no forward found")
         return
