@@ -17,6 +17,7 @@
  *                       and the fallback semantics of correlation.py:12-40
  *   pwc_corr_bwd        correlation_cuda.backward correlation_cuda.cc:89-167, kernels .cu:150-334
  *   pwc_warp_fwd        PWCDCNet.warp             models/PWCNet.py:141-177
+ *   pwc_warp_bwd        autograd of the same (grid_sample backward as used by the training scripts)
  *   pwc_conv2d_fwd      conv()/predict_flow()     models/PWCNet.py:26-33 (nn.Conv2d 3x3 + LeakyReLU(0.1))
  *   pwc_deconv4x4s2_fwd deconv()                  models/PWCNet.py:35-36 (nn.ConvTranspose2d k4 s2 p1)
  *
@@ -81,6 +82,15 @@ int pwc_warp_fwd(const void *x, const void *flo, void *out,
                  int B, int C, int H, int W,
                  float flow_scale, int align_corners, float mask_threshold, int dtype,
                  int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride,
+                 void *stream);
+
+/* Gradients of pwc_warp_fwd w.r.t. x and flo (contiguous f32 tensors; grad_x is zeroed here, then accumulated
+ * with atomics).  The validity mask is a constant, as in the reference, whose in-place thresholding
+ * (PWCNet.py:174-175) cuts the mask's graph; what autograd derives for PWCNet.py:141-177 is otherwise
+ * reproduced: d/dx through the bilinear taps, d/dflo through the sample coordinates. */
+int pwc_warp_bwd(const void *x, const void *flo, const void *grad_out, void *grad_x, void *grad_flo,
+                 int B, int C, int H, int W,
+                 float flow_scale, int align_corners, float mask_threshold, int dtype,
                  void *stream);
 
 /* Bytes needed for the packed (kernel-native) form of a [Cout,Cin,3,3] filter bank. */

@@ -29,6 +29,8 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_void_p]),
     "pwc_warp_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_float, c_int, c_float, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_warp_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                             c_float, c_int, c_float, c_int, c_void_p]),
     "pwc_conv3x3_packed_bytes": (c_int64, [c_int, c_int, c_int]),
     "pwc_conv3x3_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "pwc_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -147,7 +147,100 @@ int launch_warp(const void *x, const void *flo, void *out, int B, int C, int H, 
     return pwc::check_launch("warp_kernel");
 }
 
+// ---- backward --------------------------------------------------------------------------------------------
+// d out / d x  : scatter of mask * bilinear weight * grad_out to the four taps (atomicAdd; like torch's
+//                grid_sample backward the summation order is not fixed);
+// d out / d flo: mask * sum_c grad_out * (d sample / d ix, d sample / d iy) * d(ix,iy)/d(u,v), where
+//                d ix / d u = flow_scale * W / max(W-1,1)        (align_corners = 0)
+//                           = flow_scale * (W-1) / max(W-1,1)    (align_corners = 1).
+// The mask is a constant: the reference thresholds it in place (PWCNet.py:174-175), which cuts its graph.
+__global__ void __launch_bounds__(kWarpThreads)
+warp_bwd_kernel(const float *__restrict__ x, const float *__restrict__ flo, const float *__restrict__ go,
+                float *__restrict__ gx, float *__restrict__ gflo, int C, int H, int W, int64_t npix,
+                float flow_scale, int align_corners, float thr) {
+    const int64_t i = (int64_t)blockIdx.x * kWarpThreads + threadIdx.x;
+    if (i >= npix) return;
+    const int64_t plane = (int64_t)H * W;
+    const int b = (int)(i / plane);
+    const int pix = (int)(i - (int64_t)b * plane);
+    const int y = pix / W, xx = pix - y * W;
+    const float u = flo[(int64_t)b * 2 * plane + pix] * flow_scale;
+    const float v = flo[(int64_t)b * 2 * plane + plane + pix] * flow_scale;
+    const float px = (float)xx + u, py = (float)y + v;
+    // same coordinate arithmetic as make_taps, but the unmasked factors are needed separately
+    const float gxn = 2.0f * px / (float)max(W - 1, 1) - 1.0f;
+    const float gyn = 2.0f * py / (float)max(H - 1, 1) - 1.0f;
+    float ix, iy;
+    if (align_corners) {
+        ix = (gxn + 1.0f) / 2.0f * (float)(W - 1);
+        iy = (gyn + 1.0f) / 2.0f * (float)(H - 1);
+    } else {
+        ix = ((gxn + 1.0f) * (float)W - 1.0f) / 2.0f;
+        iy = ((gyn + 1.0f) * (float)H - 1.0f) / 2.0f;
+    }
+    const bool wild = (ix < -16.0f) || (ix > (float)W + 16.0f) || (iy < -16.0f) || (iy > (float)H + 16.0f);
+    ix = fminf(fmaxf(ix, -16.0f), (float)W + 16.0f);
+    iy = fminf(fmaxf(iy, -16.0f), (float)H + 16.0f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float ax1 = ix - fx, ay1 = iy - fy, ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
+    const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x0 + 1 >= 0) && (x0 + 1 < W);
+    const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y0 + 1 >= 0) && (y0 + 1 < H);
+    const bool v00 = vx0 && vy0, v01 = vx1 && vy0, v10 = vx0 && vy1, v11 = vx1 && vy1;
+    const float w00 = v00 ? ay0 * ax0 : 0.f, w01 = v01 ? ay0 * ax1 : 0.f;
+    const float w10 = v10 ? ay1 * ax0 : 0.f, w11 = v11 ? ay1 * ax1 : 0.f;
+    const float msum = ((w00 + w01) + w10) + w11;
+    const bool keep = (msum >= thr) && !wild;
+    float *gfu = gflo + (int64_t)b * 2 * plane + pix;
+    if (!keep) {
+        gfu[0] = 0.f;
+        gfu[plane] = 0.f;
+        return;
+    }
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    const int o00 = yc0 * W + xc0, o01 = yc0 * W + xc1, o10 = yc1 * W + xc0, o11 = yc1 * W + xc1;
+    const float *xb = x + (int64_t)b * C * plane;
+    float *gxb = gx + (int64_t)b * C * plane;
+    const float *gob = go + (int64_t)b * C * plane + pix;
+    float dix = 0.f, diy = 0.f;
+    for (int c = 0; c < C; ++c, xb += plane, gxb += plane, gob += plane) {
+        const float g = gob[0];
+        const float s00 = v00 ? xb[o00] : 0.f, s01 = v01 ? xb[o01] : 0.f;
+        const float s10 = v10 ? xb[o10] : 0.f, s11 = v11 ? xb[o11] : 0.f;
+        dix += g * (ay0 * (s01 - s00) + ay1 * (s11 - s10));
+        diy += g * (ax0 * (s10 - s00) + ax1 * (s11 - s01));
+        if (w00 != 0.f) atomicAdd(gxb + o00, g * w00);
+        if (w01 != 0.f) atomicAdd(gxb + o01, g * w01);
+        if (w10 != 0.f) atomicAdd(gxb + o10, g * w10);
+        if (w11 != 0.f) atomicAdd(gxb + o11, g * w11);
+    }
+    const float sx = align_corners ? (float)(W - 1) / (float)max(W - 1, 1) : (float)W / (float)max(W - 1, 1);
+    const float sy = align_corners ? (float)(H - 1) / (float)max(H - 1, 1) : (float)H / (float)max(H - 1, 1);
+    gfu[0] = dix * flow_scale * sx;
+    gfu[plane] = diy * flow_scale * sy;
+}
+
 }  // namespace
+
+extern "C" int pwc_warp_bwd(const void *x, const void *flo, const void *grad_out, void *grad_x, void *grad_flo,
+                            int B, int C, int H, int W,
+                            float flow_scale, int align_corners, float mask_threshold, int dtype, void *stream) {
+    if (!x || !flo || !grad_out || !grad_x || !grad_flo) PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: bad shape %dx%dx%dx%d", B, C, H, W);
+    if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_warp_bwd: dtype %d (f32 only)", dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t nblk = (npix + kWarpThreads - 1) / kWarpThreads;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: grid too large");
+    hipError_t e = hipMemsetAsync(grad_x, 0, (size_t)npix * C * sizeof(float), st);
+    if (e != hipSuccess) { pwc::set_error("pwc_warp_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)nblk), dim3(kWarpThreads), 0, st,
+                       static_cast<const float *>(x), static_cast<const float *>(flo), static_cast<const float *>(grad_out),
+                       static_cast<float *>(grad_x), static_cast<float *>(grad_flo), C, H, W, npix,
+                       flow_scale, align_corners, mask_threshold);
+    return pwc::check_launch("warp_bwd_kernel");
+}
 
 extern "C" int pwc_warp_fwd(const void *x, const void *flo, void *out,
                             int B, int C, int H, int W,

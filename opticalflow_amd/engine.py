@@ -29,6 +29,8 @@ from . import ops
 PYRAMID_CH = (3, 16, 32, 64, 96, 128, 196)
 PYRAMID_NAMES = (("conv1a", "conv1aa", "conv1b"), ("conv2a", "conv2aa", "conv2b"), ("conv3a", "conv3aa", "conv3b"),
                  ("conv4a", "conv4aa", "conv4b"), ("conv5a", "conv5aa", "conv5b"), ("conv6aa", "conv6a", "conv6b"))
+PYRAMID_NAMES_OLD = (("conv1a", None, "conv1b"), ("conv2a", None, "conv2b"), ("conv3a", None, "conv3b"),
+                     ("conv4a", None, "conv4b"), ("conv5a", None, "conv5b"), ("conv6a", None, "conv6b"))   # PWCNet.py:290-301
 DENSE_OUT = (128, 128, 96, 64, 32)            # conv{L}_0 .. conv{L}_4 (PWCNet.py:78-82)
 DENSE_TOTAL = sum(DENSE_OUT)                  # 448
 # channel offset of conv{L}_i's output inside the arena; conv{L}_i reads everything after it
@@ -36,6 +38,24 @@ DENSE_OFF = (320, 192, 96, 32, 0)
 CONTEXT = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1))   # dc_conv1..6 (PWCNet.py:126-131)
 WARP_SCALE = {5: 0.625, 4: 1.25, 3: 2.5, 2: 5.0}                      # PWCNet.py:212,226,240,256
 LEAKY = 0.1
+
+
+def old_variant_perm(k: int, od: int) -> torch.Tensor:
+    """Input-channel permutation for PWCDCNet_old (PWCNet.py:425-429): its dense block concatenates in the order
+    [conv_1 | base | conv_0 | conv_2 | conv_3 | conv_4] while the arena is [conv_4 | conv_3 | conv_2 | conv_1 | conv_0 | base].
+    Returns `perm` with arena_input_channel j == reference_input_channel perm[j] for the consumer that reads the
+    outputs of conv_0..conv_{k-1} (k = 5: flow head / upfeat / dc_conv1).  A convolution over a concatenation does
+    not care about the order as long as the filter's input channels follow it."""
+    sizes = {"base": od}
+    for i, c in enumerate(DENSE_OUT):
+        sizes["c%d" % i] = c
+    logical = [n for n in ("c1", "base", "c0", "c2", "c3", "c4") if n == "base" or int(n[1]) < k]
+    physical = ["c%d" % i for i in range(k - 1, -1, -1)] + ["base"]
+    start, pos = {}, 0
+    for n in logical:
+        start[n] = pos
+        pos += sizes[n]
+    return torch.cat([torch.arange(start[n], start[n] + sizes[n]) for n in physical])
 
 
 def level_in_channels(level: int, nd: int = 81) -> int:
@@ -46,7 +66,9 @@ def level_in_channels(level: int, nd: int = 81) -> int:
 class PwcPlan:
     def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device,
                  dtype: torch.dtype = torch.float32, md: int = 4, normalize_corr: bool = False,
-                 align_corners: bool = False, conv_backend: str = "hip"):
+                 align_corners: bool = False, conv_backend: str = "hip", variant: str = "dc"):
+        if variant not in ("dc", "old"):
+            raise ValueError("variant must be 'dc' (PWCDCNet) or 'old' (PWCDCNet_old)")
         if H % 64 or W % 64 or H <= 0 or W <= 0:
             raise ValueError("PWCDCNet needs H and W to be positive multiples of 64 (got %dx%d); resize or pad the "
                              "pair first like script_pwc.py:47-54 / inference_kitti.py:53-63" % (H, W))
@@ -61,7 +83,23 @@ class PwcPlan:
         self.normalize_corr = normalize_corr
         self.align_corners = align_corners
         self.conv_backend = conv_backend
-        self.p = params
+        self.variant = variant
+        self.pyramid_names = PYRAMID_NAMES if variant == "dc" else PYRAMID_NAMES_OLD
+        self.mask_threshold = 0.9999 if variant == "dc" else 0.999        # PWCNet.py:174 / :400
+        self.p = dict(params)
+        if variant == "old":
+            # re-order the filters' input channels from the reference's concatenation order to the arena's
+            for l in range(2, 7):
+                od = level_in_channels(l, self.nd)
+                names = [("conv%d_%d.0.weight" % (l, k), k, 1) for k in range(1, 5)]
+                names.append(("predict_flow%d.weight" % l, 5, 1))
+                if l > 2:
+                    names.append(("upfeat%d.weight" % l, 5, 0))
+                else:
+                    names.append(("dc_conv1.0.weight", 5, 1))
+                for key, k, dim in names:
+                    perm = old_variant_perm(k, od).to(device)
+                    self.p[key] = self.p[key].index_select(dim, perm).contiguous()
         kw = dict(device=device, dtype=dtype)
 
         self.size = {l: (H >> l, W >> l) for l in range(1, 7)}
@@ -87,7 +125,7 @@ class PwcPlan:
         self.packed: Dict[str, torch.Tensor] = {}
         self.workspace: Optional[torch.Tensor] = None
         if conv_backend == "hip":
-            for key, t in params.items():
+            for key, t in self.p.items():
                 if key.endswith(".weight") and t.dim() == 4 and t.shape[2:] == (3, 3):
                     self.packed[key[:-len(".weight")]] = ops.pack_conv3x3(t)
             # one split-K scratch shared by every stride-1 conv of the decoder (they run back to back on one stream)
@@ -150,14 +188,17 @@ class PwcPlan:
         (rgb [n,3,H,W], slot_lo, slot_hi) sources for the first conv."""
         prev = None
         for l in range(1, 7):
-            na, naa, nb = PYRAMID_NAMES[l - 1]
+            na, naa, nb = self.pyramid_names[l - 1]
             a, bb = self.pyr_a[l][lo:hi], self.pyr_b[l][lo:hi]
+            # three convs a -> bb -> a (PWCNet.py:184-195); two for PWCDCNet_old, bb -> a (PWCNet.py:411-422)
+            first = self.pyr_a[l] if naa is not None else self.pyr_b[l]
             if l == 1:
                 for img, s0, s1 in images:
-                    self._conv(na, img, self.pyr_a[1][s0:s1], stride=2)
+                    self._conv(na, img, first[s0:s1], stride=2)
             else:
-                self._conv(na, prev, a, stride=2)
-            self._conv(naa, a, bb)
+                self._conv(na, prev, first[lo:hi], stride=2)
+            if naa is not None:
+                self._conv(naa, a, bb)
             self._conv(nb, bb, a)
             prev = a
 
@@ -179,7 +220,7 @@ class PwcPlan:
                 ar[:, off:off + c].copy_(self.c1[l])
                 up_flow = ar[:, off + c:off + c + 2]
                 ops.warp(self.c2[l], up_flow, flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
-                         out=self.warped[l])
+                         mask_threshold=self.mask_threshold, out=self.warped[l])
                 ops.correlation(ar[:, off:off + c], self.warped[l], self.md, 1, self.md, 1, 1, 1.0,
                                 normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
             lo = base
@@ -234,8 +275,8 @@ class PwcVideoPlan(PwcPlan):
     """
 
     def __init__(self, params, B, H, W, device, dtype=torch.float32, md=4, normalize_corr=False,
-                 align_corners=False, conv_backend="hip"):
-        super().__init__(params, B, H, W, device, dtype, md, normalize_corr, align_corners, conv_backend)
+                 align_corners=False, conv_backend="hip", variant="dc"):
+        super().__init__(params, B, H, W, device, dtype, md, normalize_corr, align_corners, conv_backend, variant)
         self.primed = False
 
     @staticmethod

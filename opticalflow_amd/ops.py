@@ -138,6 +138,45 @@ def warp(x: torch.Tensor, flo: torch.Tensor, flow_scale: float = 1.0, align_corn
     return out
 
 
+def warp_backward(x: torch.Tensor, flo: torch.Tensor, grad_out: torch.Tensor, flow_scale: float = 1.0,
+                  align_corners: bool = False, mask_threshold: float = 0.9999):
+    """(grad_x, grad_flo) of `warp` for contiguous float32 tensors."""
+    lib = _lib.load()
+    for name, t in (("x", x), ("flo", flo), ("grad_out", grad_out)):
+        _plane_dense(t, name)
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError("%s must be contiguous float32 for the backward kernel" % name)
+    B, C, H, W = x.shape
+    if tuple(flo.shape) != (B, 2, H, W) or tuple(grad_out.shape) != (B, C, H, W):
+        raise ValueError("flo must be %s and grad_out %s" % ((B, 2, H, W), (B, C, H, W)))
+    gx = torch.empty_like(x)
+    gf = torch.empty_like(flo)
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_warp_bwd(x.data_ptr(), flo.data_ptr(), grad_out.data_ptr(), gx.data_ptr(), gf.data_ptr(),
+                              B, C, H, W, float(flow_scale), 1 if align_corners else 0, float(mask_threshold),
+                              _dtype_code(x), _stream(x))
+    check(rc, "pwc_warp_bwd")
+    return gx, gf
+
+
+class WarpFunction(torch.autograd.Function):
+    """autograd wrapper of the fused warp: forward and backward both run HIP kernels (what autograd builds from
+    PWCNet.py:141-177 in the reference's training scripts)."""
+
+    @staticmethod
+    def forward(ctx, x, flo, flow_scale=1.0, align_corners=False, mask_threshold=0.9999):
+        x, flo = x.contiguous(), flo.contiguous()
+        ctx.save_for_backward(x, flo)
+        ctx.cfg = (flow_scale, align_corners, mask_threshold)
+        return warp(x, flo, flow_scale, align_corners, mask_threshold)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, flo = ctx.saved_tensors
+        gx, gf = warp_backward(x, flo, grad_out.contiguous(), *ctx.cfg)
+        return gx, gf, None, None, None
+
+
 def pack_conv3x3(weight: torch.Tensor) -> torch.Tensor:
     """[Cout,Cin,3,3] nn.Conv2d filter bank -> kernel-native packed buffer (device, float32)."""
     lib = _lib.load()

@@ -31,10 +31,11 @@ import torch.nn as nn
 from . import ops
 from ._lib import PwcHipError
 from .correlation import Correlation
-from .engine import CONTEXT, DENSE_OUT, PYRAMID_CH, PYRAMID_NAMES, PwcPlan, level_in_channels
+from .engine import (CONTEXT, DENSE_OUT, PYRAMID_CH, PYRAMID_NAMES, PYRAMID_NAMES_OLD, PwcPlan,
+                     level_in_channels)
 from .weights import load_checkpoint, synthetic_state_dict
 
-__all__ = ["PWCDCNet", "pwc_dc_net"]
+__all__ = ["PWCDCNet", "PWCDCNet_old", "pwc_dc_net", "pwc_dc_net_old"]
 
 
 def _conv_block(cin: int, cout: int, stride: int = 1, dilation: int = 1) -> nn.Sequential:
@@ -43,6 +44,9 @@ def _conv_block(cin: int, cout: int, stride: int = 1, dilation: int = 1) -> nn.S
 
 
 class PWCDCNet(nn.Module):
+    variant = "dc"
+    _pyramid_names = PYRAMID_NAMES
+
     def __init__(self, md: int = 4, normalize_corr: bool = False, align_corners: bool = False,
                  conv_backend: str = "hip", use_graph: bool = False):
         super().__init__()
@@ -53,10 +57,11 @@ class PWCDCNet(nn.Module):
         self.use_graph = use_graph
 
         # registration order == reference order (PWCNet.py:52-132)
-        for lvl, (na, naa, nb) in enumerate(PYRAMID_NAMES, start=1):
+        for lvl, (na, naa, nb) in enumerate(self._pyramid_names, start=1):
             cin, cout = PYRAMID_CH[lvl - 1], PYRAMID_CH[lvl]
             self.add_module(na, _conv_block(cin, cout, stride=2))
-            self.add_module(naa, _conv_block(cout, cout))
+            if naa is not None:
+                self.add_module(naa, _conv_block(cout, cout))
             self.add_module(nb, _conv_block(cout, cout))
         self.corr = Correlation(pad_size=md, kernel_size=1, max_displacement=md, stride1=1, stride2=1,
                                 corr_multiply=1, normalize=normalize_corr)
@@ -93,7 +98,10 @@ class PWCDCNet(nn.Module):
     # ---- reference surface --------------------------------------------------------------------
     def warp(self, x: torch.Tensor, flo: torch.Tensor) -> torch.Tensor:
         """warp an image/tensor (im2) back to im1 according to the optical flow (PWCNet.py:141-177)."""
-        return ops.warp(ops.densify(x), ops.densify(flo), 1.0, self.align_corners)
+        thr = 0.9999 if self.variant == "dc" else 0.999
+        if torch.is_grad_enabled() and (x.requires_grad or flo.requires_grad):
+            return ops.WarpFunction.apply(x, flo, 1.0, self.align_corners, thr)
+        return ops.warp(ops.densify(x), ops.densify(flo), 1.0, self.align_corners, thr)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor):
@@ -146,7 +154,7 @@ class PWCDCNet(nn.Module):
                 if v.dtype != torch.float32:
                     raise NotImplementedError("parameters must be float32 (got %s for %s)" % (v.dtype, k))
             plan = PwcPlan(params, x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype, self.md,
-                           self.normalize_corr, self.align_corners, self.conv_backend)
+                           self.normalize_corr, self.align_corners, self.conv_backend, self.variant)
             self._plans[key] = plan
         return plan
 
@@ -180,6 +188,23 @@ class PWCDCNet(nn.Module):
 
     def manifest(self) -> List[Tuple[str, Tuple[int, ...]]]:
         return [(k, tuple(v.shape)) for k, v in self.state_dict().items()]
+
+
+class PWCDCNet_old(PWCDCNet):
+    """The reference's earlier variant (``models/PWCNet.py:277-491``): 116-key state-dict (no ``conv*aa``),
+    dense-block concatenation order ``cat(x, conv_0(x)); cat(conv_1(x), x); cat(x, conv_2(x)); ...`` and warp mask
+    threshold 0.999.  Runs on the same kernels and arena: only the filters' input-channel order is re-mapped
+    when the plan packs them (engine.old_variant_perm)."""
+    variant = "old"
+    _pyramid_names = PYRAMID_NAMES_OLD
+
+
+def pwc_dc_net_old(path: Optional[str] = None, **kwargs) -> PWCDCNet_old:
+    """Factory with the reference's name and argument (PWCNet.py:511-520)."""
+    model = PWCDCNet_old(**kwargs)
+    if path is not None:
+        model.load_state_dict(load_checkpoint(path))
+    return model
 
 
 def pwc_dc_net(path: Optional[str] = None, **kwargs) -> PWCDCNet:

@@ -48,7 +48,8 @@ class FlowStream:
         self.device = p0.device
         self.batch, self.height, self.width = batch, height, width
         self.plan = PwcVideoPlan(params, batch, height, width, self.device, torch.float32, net.md,
-                                 net.normalize_corr, net.align_corners, net.conv_backend)
+                                 net.normalize_corr, net.align_corners, net.conv_backend,
+                                 getattr(net, "variant", "dc"))
         self.use_graph = use_graph
         self._graph = None
         self._static = torch.empty((batch, 3, height, width), device=self.device, dtype=torch.float32)

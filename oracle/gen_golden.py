@@ -10,7 +10,7 @@ Recipe: two process-local shims, no reference file is edi
     CUDA extension at import time; it is never called because USE_ONNX_CORRELATION is set);
   * ``torch.Tensor.cuda`` = identity (reference PWCNet.py:167 calls .cuda() unconditionally).
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [old]
 """
 import hashlib
 import os
@@ -174,14 +174,64 @@ def gen_flo():
     print("g4_flo: %d bytes" % len(blob))
 
 
+def gen_old():
+    """PWCDCNet_old (PWCNet.py:277-491): 116-key variant without the *aa pyramid convs, mixed concat order,
+    warp mask threshold 0.999.  Same synthetic-weight recipe as g3."""
+    from models.PWCNet import PWCDCNet_old as RefOld
+    net = RefOld().eval()
+    manifest = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = synthetic_state_dict(manifest, seed=WSEED, gain=GAIN, bias_std=BIAS_STD)
+    net.load_state_dict(sd, strict=True)
+    cases = {"gain": np.array(GAIN), "bias_std": np.array(BIAS_STD), "wseed": np.array(WSEED),
+             "keys": np.array([k for k, _ in manifest]),
+             "shapes": np.array([",".join(map(str, s)) for _, s in manifest])}
+    cases["weights_digest"] = np.array(hashlib.sha256(b"".join(sd[k].numpy().tobytes() for k, _ in manifest)).hexdigest())
+    for tag, shape, seed in (("s", (1, 6, 64, 64), 2234), ("m", (2, 6, 128, 192), 2235)):
+        x = rand(shape, seed)
+        cases["xseed_" + tag] = np.array(seed)
+        cases["xshape_" + tag] = np.array(shape)
+        cases["xdigest_" + tag] = np.array(digest(x))
+        with torch.no_grad():
+            f2 = net(x)
+            net.train()
+            outs = net(x)
+            net.eval()
+        cases["flow2_" + tag] = f2.numpy()
+        for lvl, o in zip((2, 3, 4, 5, 6), outs):
+            cases["train_flow%d_%s" % (lvl, tag)] = o.numpy()
+        torch.set_default_dtype(torch.float64)
+        try:
+            net64 = RefOld().double().eval()
+            net64.load_state_dict({k: v.double() for k, v in sd.items()})
+            with torch.no_grad():
+                f2d = net64(x.double())
+        finally:
+            torch.set_default_dtype(torch.float32)
+        cases["flow2_f64_" + tag] = f2d.numpy()
+        e = torch.sqrt(((f2.double() - f2d) ** 2).sum(1)).mean().item()
+        print("g6_old[%s]: mean|flow2| %.4f, fp32-vs-fp64 EPE %.3e" % (tag, f2.abs().mean().item(), e))
+    # warp with the old threshold (PWCNet.py:400: mask < 0.999)
+    xx = rand((2, 5, 12, 20), 2400, -1, 1)
+    ff = rand((2, 2, 12, 20), 2401, -3, 3)
+    with torch.no_grad():
+        cases["warp_x"], cases["warp_flo"] = xx.numpy(), ff.numpy()
+        cases["warp_out"] = net.warp(xx, ff.clone()).numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_old.npz"), **cases)
+    print("g6_old: %d keys" % len(manifest))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["old"]:          # only the PWCDCNet_old fixture (leaves g1..g5 untouched)
+        gen_old()
+        return
     gen_corr()
     net, manifest = gen_forward()
     gen_warp(net)
     gen_manifest(manifest)
     gen_flo()
+    gen_old()
 
 
 if __name__ == "__main__":

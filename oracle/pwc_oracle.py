@@ -15,6 +15,8 @@ It restates, on the CPU, the algorithm of the reference hot path:
   explicit bilinear arithmetic, not as a call to ``grid_sample``.
 * ``pwc_forward``      <- reference ``models/PWCNet.py:180-273`` (functional,
   driven by a state-dict with the reference's 128 keys).
+* ``pwc_forward_old`` / ``state_dict_manifest_old`` <- ``models/PWCNet.py:277-491`` (``PWCDCNet_old``:
+  no ``*aa`` pyramid convs, mixed concatenation order, warp mask threshold 0.999).
 * ``read_flo`` / ``write_flo`` <- ``script_pwc.py:12-27`` / ``data_processing.py:17-29``.
 
 Pinning: the reference holds no golden vectors of its own,
@@ -234,9 +236,71 @@ def pwc_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, normalize_corr: bo
     return flow2
 
 
+PYRAMID_OLD = (("conv1a", 2), ("conv1b", 1), ("conv2a", 2), ("conv2b", 1), ("conv3a", 2), ("conv3b", 1),
+               ("conv4a", 2), ("conv4b", 1), ("conv5a", 2), ("conv5b", 1), ("conv6a", 2), ("conv6b", 1))   # PWCNet.py:290-301
+OLD_MASK_THRESHOLD = 0.999                                                                                 # PWCNet.py:400
+
+
+def pwc_forward_old(sd: Dict[str, torch.Tensor], x: torch.Tensor, normalize_corr: bool = False,
+                    align_corners: bool = False, all_levels: bool = False, md: int = 4):
+    """PWCDCNet_old.forward (PWCNet.py:407-491).  Concatenation order per level (PWCNet.py:425-429 etc.):
+    x = cat(x, conv_0(x)); x = cat(conv_1(x), x); x = cat(x, conv_2(x)); x = cat(x, conv_3(x)); x = cat(x, conv_4(x))."""
+    feats = []
+    for im in (x[:, :3], x[:, 3:]):
+        pyr = []
+        t = im
+        for i, (name, stride) in enumerate(PYRAMID_OLD):
+            t = _conv(sd, name, t, stride=stride)
+            if i % 2 == 1:
+                pyr.append(t)
+        feats.append(pyr)
+    flows = {}
+    up_flow = up_feat = None
+    xcat = None
+    for lvl in (6, 5, 4, 3, 2):
+        c1 = feats[0][lvl - 1]
+        c2 = feats[1][lvl - 1]
+        if lvl == 6:
+            xcat = leaky_relu(correlation(c1, c2, md, 1, md, 1, 1, 1, normalize=normalize_corr))
+        else:
+            w = warp(c2, up_flow * WARP_SCALE[lvl], align_corners=align_corners, mask_threshold=OLD_MASK_THRESHOLD)
+            corr = leaky_relu(correlation(c1, w, md, 1, md, 1, 1, 1, normalize=normalize_corr))
+            xcat = torch.cat((corr, c1, up_flow, up_feat), 1)
+        xcat = torch.cat((xcat, _conv(sd, "conv%d_0" % lvl, xcat)), 1)
+        xcat = torch.cat((_conv(sd, "conv%d_1" % lvl, xcat), xcat), 1)
+        for i in (2, 3, 4):
+            xcat = torch.cat((xcat, _conv(sd, "conv%d_%d" % (lvl, i), xcat)), 1)
+        flow = _conv(sd, "predict_flow%d" % lvl, xcat, act=False)
+        flows[lvl] = flow
+        if lvl > 2:
+            up_flow = _deconv(sd, "deconv%d" % lvl, flow)
+            up_feat = _deconv(sd, "upfeat%d" % lvl, xcat)
+    t = xcat
+    for i, dil in enumerate(DILATIONS):
+        t = _conv(sd, "dc_conv%d" % (i + 1), t, dilation=dil)
+    flow2 = flows[2] + _conv(sd, "dc_conv7", t, act=False)
+    if all_levels:
+        return flow2, flows[3], flows[4], flows[5], flows[6]
+    return flow2
+
+
 # --------------------------------------------------------------------------
 # state-dict manifest (PWCNet.py:52-132) -- 128 (key, shape) pairs
 # --------------------------------------------------------------------------
+
+def state_dict_manifest_old(md: int = 4) -> List[Tuple[str, Tuple[int, ...]]]:
+    """PWCDCNet_old (PWCNet.py:288-366): the 128-key manifest minus the six *aa pyramid convs -> 116 keys."""
+    drop = {"conv1aa", "conv2aa", "conv3aa", "conv4aa", "conv5aa"}
+    out = []
+    for k, shp in state_dict_manifest(md):
+        head = k.split(".")[0]
+        if head in drop or head == "conv6a":
+            continue                                   # conv6aa (128->196, stride 2) takes the name conv6a below
+        if head == "conv6aa":
+            k = "conv6a" + k[len("conv6aa"):]
+        out.append((k, shp))
+    return out
+
 
 def state_dict_manifest(md: int = 4) -> List[Tuple[str, Tuple[int, ...]]]:
     out: List[Tuple[str, Tuple[int, ...]]] = []

@@ -178,6 +178,38 @@ def test_warp_scale_align_and_strided_operands(dev):
     assert (idt - x).abs().max().item() < 1e-5      # (x*2/(W-1)-1+1)/2*(W-1) is x only up to fp32 rounding
 
 
+@pytest.mark.parametrize("align,thr,scale", [(False, 0.9999, 1.0), (True, 0.999, 2.5)])
+def test_warp_backward_matches_autograd_of_oracle(dev, align, thr, scale):
+    """pwc_warp_bwd vs torch autograd through the oracle's explicit-bilinear warp (mask constant, PWCNet.py:174-175).
+    Flows keep sample points away from integer coordinates by construction of the check: positions whose
+    fractional part is within 1e-3 of a pixel boundary are excluded (the derivative is discontinuous there)."""
+    from opticalflow_amd import ops
+    B, C, H, W = 2, 5, 11, 14
+    x = seeded_rand((B, C, H, W), 140, -1, 1)
+    flo = seeded_rand((B, 2, H, W), 141, -3, 3)
+    go = seeded_rand((B, C, H, W), 142, -1, 1)
+    xr, fr = x.clone().requires_grad_(True), flo.clone().requires_grad_(True)
+    O.warp(xr, fr * scale, align_corners=align, mask_threshold=thr).backward(go)
+    gx, gf = ops.warp_backward(x.to(dev), flo.to(dev), go.to(dev), scale, align, thr)
+    assert torch.allclose(gx.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    sx = (W if not align else W - 1) / (W - 1)
+    sy = (H if not align else H - 1) / (H - 1)
+    ix = (torch.arange(W).view(1, 1, W) + flo[:, 0] * scale) * sx - (0.0 if align else 0.5)
+    iy = (torch.arange(H).view(1, H, 1) + flo[:, 1] * scale) * sy - (0.0 if align else 0.5)
+    smooth = (((ix - ix.round()).abs() > 1e-3) & ((iy - iy.round()).abs() > 1e-3)).unsqueeze(1)
+    assert smooth.float().mean().item() > 0.99
+    assert torch.allclose(gf.cpu() * smooth, fr.grad * smooth, rtol=1e-4, atol=1e-5)
+    assert gf.abs().max().item() > 0.1
+    # autograd registration: model.warp is differentiable end to end on the device
+    from opticalflow_amd import PWCDCNet
+    net = PWCDCNet(align_corners=align)
+    xd, fd = x.to(dev).requires_grad_(True), flo.to(dev).requires_grad_(True)
+    net.warp(xd, fd).backward(go.to(dev))
+    xr2, fr2 = x.clone().requires_grad_(True), flo.clone().requires_grad_(True)
+    O.warp(xr2, fr2, align_corners=align).backward(go)
+    assert torch.allclose(xd.grad.cpu(), xr2.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_model_warp_method(dev):
     from opticalflow_amd import PWCDCNet
     net = PWCDCNet()
@@ -352,6 +384,31 @@ def test_forward_golden_epe(dev, backend):
               % (backend, tag, e32, e64, O.epe(ref32, ref64)))
         assert f2.shape == ref32.shape
         assert e32 < 1e-3 and e64 < 1e-3
+
+
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+def test_forward_old_variant_golden_epe(dev, backend):
+    """PWCDCNet_old through the same kernels (filters re-mapped to the arena order) vs the reference's output
+    (golden g6) -- bar 1e-3 mean EPE, observed ~1e-6."""
+    from opticalflow_amd import pwcnet
+    from opticalflow_amd.weights import synthetic_state_dict
+    g = load_golden("g6_old.npz")
+    net = pwcnet.PWCDCNet_old(conv_backend=backend).to(dev).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=int(g["wseed"]), gain=float(g["gain"]),
+                                             bias_std=float(g["bias_std"])))
+    for tag in ("s", "m"):
+        x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag]).to(dev)
+        f2 = net(x).cpu()
+        ref = torch.from_numpy(g["flow2_" + tag])
+        assert f2.shape == ref.shape
+        assert O.epe(f2, ref) < 1e-3, (tag, O.epe(f2, ref))
+        assert O.epe(f2, torch.from_numpy(g["flow2_f64_" + tag])) < 1e-3
+    net.train()
+    outs = net(x)
+    for lvl, o in zip((2, 3, 4, 5, 6), outs):
+        assert O.epe(o.cpu(), torch.from_numpy(g["train_flow%d_m" % lvl])) < 1e-3, lvl
+    xx, ff = torch.from_numpy(g["warp_x"]).to(dev), torch.from_numpy(g["warp_flo"]).to(dev)
+    assert (net.warp(xx, ff).cpu() - torch.from_numpy(g["warp_out"])).abs().max().item() < 1e-5
 
 
 def test_forward_training_tuple_and_graph(dev):

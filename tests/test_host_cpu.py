@@ -160,5 +160,33 @@ def test_drop_in_import_paths():
     assert callable(models.pwc_dc_net) and callable(correlation_cuda.forward) and callable(correlation_cuda.backward)
     m = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1)
     assert (m.pad_size, m.kernel_size, m.max_displacement, m.stride1, m.stride2, m.corr_multiply) == (4, 1, 4, 1, 1, 1)
-    with pytest.raises(NotImplementedError):
-        models.pwc_dc_net_old()
+    old = models.pwc_dc_net_old()                      # PWCNet.py:511-520
+    assert type(old).__name__ == "PWCDCNet_old" and len(old.state_dict()) == 116
+
+
+def test_old_variant_state_dict_and_channel_permutation():
+    """PWCDCNet_old: the reference's 116 keys in its order (golden g6), strict load; the filter re-mapping
+    used by the plan is a true permutation that sends the reference's concatenation order to the arena's."""
+    from conftest import load_golden
+    from opticalflow_amd import pwcnet
+    from opticalflow_amd.engine import DENSE_OUT, old_variant_perm
+    g = load_golden("g6_old.npz")
+    net = pwcnet.PWCDCNet_old()
+    assert [k for k, _ in net.manifest()] == [str(k) for k in g["keys"]]
+    assert [",".join(map(str, s)) for _, s in net.manifest()] == [str(s) for s in g["shapes"]]
+    net.load_state_dict({k: torch.zeros(s) for k, s in net.manifest()}, strict=True)
+    od = 81 + 32 + 4
+    for k in range(1, 6):
+        perm = old_variant_perm(k, od)
+        n = od + sum(DENSE_OUT[:k])
+        assert sorted(perm.tolist()) == list(range(n))
+    # k=2: reference order [conv_1 | base | conv_0] -> arena [conv_1 | conv_0 | base]
+    p2 = old_variant_perm(2, od).tolist()
+    assert p2[:128] == list(range(0, 128)) and p2[128:256] == list(range(128 + od, 256 + od)) and p2[256:] == list(range(128, 128 + od))
+    # functional check on CPU: conv over the arena order with permuted filters == conv over the reference order
+    xs = {n: torch.randn(1, c, 5, 6) for n, c in (("base", od), ("c0", 128), ("c1", 128), ("c2", 96))}
+    w = torch.randn(8, od + 128 + 128 + 96, 3, 3)
+    ref = torch.nn.functional.conv2d(torch.cat([xs["c1"], xs["base"], xs["c0"], xs["c2"]], 1), w, padding=1)
+    got = torch.nn.functional.conv2d(torch.cat([xs["c2"], xs["c1"], xs["c0"], xs["base"]], 1),
+                                     w.index_select(1, old_variant_perm(3, od)), padding=1)
+    assert (ref - got).abs().max().item() < 1e-3

@@ -87,6 +87,29 @@ def test_g3_forward_matches_reference():
         assert O.epe(outs[0], torch.from_numpy(g["flow2_f64_" + tag])) < 1e-4
 
 
+def test_g6_old_variant_matches_reference():
+    """PWCDCNet_old (PWCNet.py:277-491) restatement vs the reference's own output."""
+    g = load_golden("g6_old.npz")
+    man = O.state_dict_manifest_old()
+    assert [k for k, _ in man] == [str(k) for k in g["keys"]] and len(man) == 116
+    assert [",".join(map(str, s)) for _, s in man] == [str(s) for s in g["shapes"]]
+    sd = synthetic_state_dict(man, seed=int(g["wseed"]), gain=float(g["gain"]), bias_std=float(g["bias_std"]))
+    assert hashlib.sha256(b"".join(sd[k].numpy().tobytes() for k, _ in man)).hexdigest() == str(g["weights_digest"])
+    torch.set_num_threads(8)
+    for tag in ("s", "m"):
+        x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag])
+        assert _digest(x) == str(g["xdigest_" + tag])
+        with torch.no_grad():
+            outs = O.pwc_forward_old(sd, x, all_levels=True)
+        for lvl, o in zip((2, 3, 4, 5, 6), outs):
+            assert O.epe(o, torch.from_numpy(g["train_flow%d_%s" % (lvl, tag)])) < 1e-5, (tag, lvl)
+        assert O.epe(outs[0], torch.from_numpy(g["flow2_" + tag])) < 1e-5
+        assert O.epe(outs[0], torch.from_numpy(g["flow2_f64_" + tag])) < 1e-4
+    w = O.warp(torch.from_numpy(g["warp_x"]), torch.from_numpy(g["warp_flo"]), mask_threshold=O.OLD_MASK_THRESHOLD)
+    ref = torch.from_numpy(g["warp_out"])
+    assert ((w == 0) == (ref == 0)).all() and (w - ref).abs().max().item() < 2e-6
+
+
 def test_g4_flo_bytes():
     g = load_golden("g4_flo.npz")
     uv, blob = g["uv"], g["blob"].tobytes()
