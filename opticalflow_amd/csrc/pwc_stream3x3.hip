@@ -10,11 +10,13 @@
 //     4-channel chunk through a 4-deep LDS ring filled by buffer_load_dwordx4 ... lds issued from inline asm
 //     (pwc_common.h): three chunks in flight, counted vmcnt, one barrier per chunk; zero padding and the ragged
 //     last chunk come from the buffer range check;
-//   * the chunk's filter taps travel in the SAME ring slot (the DMA instruction slot that waves 2 and 3 would
-//     otherwise spend on padding carries 80 + 128 floats of weights), and are read back as LDS broadcasts:
-//     with one wave per SIMD, per-channel scalar loads from global were fully exposed (3x slower);
-//   * per channel a thread reads its 3 x 6 window (ds_read_b128 + 2 ds_read_b32 per row) and does
-//     72 fma (HEAD) and/or 128 fma (UPFEAT);
+//   * the chunk's filter taps travel in the SAME ring slot (the last two 1-KiB strips of the slot, which hold no
+//     tile data, carry 80 + 128 floats of weights), and are read back as LDS broadcasts: with one wave per SIMD,
+//     per-channel scalar loads from global were fully exposed (3x slower).  The tap DMA is dword-granular with
+//     per-lane source offsets that INTERLEAVE the two output channels ([tap][co]), so that
+//   * per channel a thread reads its 3 x 6 window (ds_read_b128 + 2 ds_read_b32 per row) and does 36 (HEAD)
+//     and/or 64 (UPFEAT) v_pk_fma_f32 on (co0, co1) accumulator pairs: input broadcast x tap pair.  Plain
+//     v_fma_f32 runs at half that rate on gfx950 and these kernels are VALU-bound once the stream is hidden;
 //   * epilogue: bias, optional LeakyReLU / residual (HEAD), 16-byte stores.
 // Needs W % 4 == 0, W >= 128 and 16-byte aligned tensors; the dispatchers in pwc_conv.hip / pwc_deconv.hip
 // use other kernels otherwise.
@@ -35,37 +37,39 @@ constexpr int kPitch = kTW + 8;         // floats: cols x0-4 .. x0+131
 constexpr int kQuads = kPitch / 4;      // 34 pieces per row
 constexpr int kPieces = kCK * kRows * kQuads;                   // 1360
 constexpr int kSlots = (kPieces + kThreads - 1) / kThreads;     // 6 x 256 pieces per ring slot
-constexpr int kInstr = kSlots * 4;                              // 24 wave-instructions of 64 x 16 B per chunk, all by the loader
+constexpr int kInstr = kSlots * 4;                              // 24 x 1-KiB strips per ring slot: 22 tile strips + 2 tap strips
+constexpr int kVmem = kInstr + 2;                               // VMEM instructions per chunk: 22 x b128 + 4 x b32 (taps)
 constexpr int kBuf = kSlots * kThreads * 4;                     // 6144 floats = 24 KiB per ring slot
 constexpr int kHeadWOff = (kSlots - 1) * kThreads * 4 + 2 * 256;    // floats: wave 2's last-slot strip (5632)
 constexpr int kUpWOff = (kSlots - 1) * kThreads * 4 + 3 * 256;      // floats: wave 3's last-slot strip (5888)
-constexpr int kHeadWRow = 20;           // packed head taps per channel: {co0: 9 taps, 0, co1: 9 taps, 0}
-constexpr int kUpWRow = 32;             // nn layout [ci][co][4][4]
+constexpr int kHeadWRow = 20;           // global: {co0: 9 taps, 0, co1: 9 taps, 0} per channel; LDS: [tap][co] + 2 zeros
+constexpr int kUpWRow = 32;             // global: nn layout [ci][co][4][4]; LDS: [ky*4+kx][co]
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kOOB = 0x80000000u;
 static_assert(kRing == 3, "the loader's counted wait assumes exactly one younger chunk in flight");
 static_assert(kPieces * 4 <= kHeadWOff, "weights strip overlaps the tile");
 
 constexpr int MODE_HEAD = 1, MODE_UPFEAT = 2;
 
-// Loader wave: start the LDS-DMA of one chunk.  Instructions 0..21 carry the tile (pieces 64*i + lane), 22 the
-// head taps, 23 the upfeat taps (their pieces would be padding).
+// Loader wave: start the LDS-DMA of one chunk.  Instructions 0..21 carry the tile (pieces 64*i + lane); then four
+// dword DMAs carry the taps into strips 22 (head, 80 floats) and 23 (upfeat, 128 floats), re-ordered to [tap][co]
+// by their per-lane source offsets (woff).  A mode that is off still issues its two (all out-of-range) DMAs so that
+// the counted vmcnt is the same for every instantiation.
 template <int MODE>
 __device__ __forceinline__ void issue(const float *xb, const float *hw, const float *uw, int chunk, int Cin, int plane,
-                                      float *buf, const unsigned (&off)[kInstr]) {
+                                      float *buf, const unsigned (&off)[kInstr - 2], const unsigned (&woff)[4]) {
     const int c0 = chunk * kCK;
     const int cvalid = min(kCK, Cin - c0);
     const pwc::v4i32 r = pwc::make_rsrc(xb + (int64_t)c0 * plane, cvalid * plane * 4);
     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
 #pragma unroll
     for (int i = 0; i < kInstr - 2; ++i) pwc::dma_b128(r, base + i * 1024, off[i]);
-    if constexpr (MODE & MODE_HEAD)
-        pwc::dma_b128(pwc::make_rsrc(hw + (int64_t)c0 * kHeadWRow, cvalid * kHeadWRow * 4), base + (kInstr - 2) * 1024, off[kInstr - 2]);
-    else
-        pwc::dma_b128(r, base + (kInstr - 2) * 1024, off[kInstr - 2]);
-    if constexpr (MODE & MODE_UPFEAT)
-        pwc::dma_b128(pwc::make_rsrc(uw + (int64_t)c0 * kUpWRow, cvalid * kUpWRow * 4), base + (kInstr - 1) * 1024, off[kInstr - 1]);
-    else
-        pwc::dma_b128(r, base + (kInstr - 1) * 1024, off[kInstr - 1]);
+    const pwc::v4i32 rh = (MODE & MODE_HEAD) ? pwc::make_rsrc(hw + (int64_t)c0 * kHeadWRow, cvalid * kHeadWRow * 4) : r;
+    pwc::dma_b32(rh, base + (kInstr - 2) * 1024, woff[0]);
+    pwc::dma_b32(rh, base + (kInstr - 2) * 1024 + 256, woff[1]);
+    const pwc::v4i32 ru = (MODE & MODE_UPFEAT) ? pwc::make_rsrc(uw + (int64_t)c0 * kUpWRow, cvalid * kUpWRow * 4) : r;
+    pwc::dma_b32(ru, base + (kInstr - 1) * 1024, woff[2]);
+    pwc::dma_b32(ru, base + (kInstr - 1) * 1024 + 256, woff[3]);
 }
 
 template <int MODE>
@@ -97,9 +101,9 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
 
     if (wave == 4) {
         // ================= producer wave: runs the ring, two chunks ahead of the consumers ==================
-        unsigned off[kInstr];
+        unsigned off[kInstr - 2];
 #pragma unroll
-        for (int i = 0; i < kInstr; ++i) {
+        for (int i = 0; i < kInstr - 2; ++i) {
             const int p = i * 64 + lane;
             const int c = p / (kRows * kQuads);
             const int rem = p % (kRows * kQuads);
@@ -110,33 +114,43 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
             const bool ok = (p < kPieces) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);   // W % 4 == 0
             off[i] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
         }
-        // the tap fetches are plain contiguous copies: lane -> 16-byte piece `lane`
-        if (MODE & MODE_HEAD) off[kInstr - 2] = (lane < kCK * kHeadWRow / 4) ? lane * 16u : kOOB;
-        if (MODE & MODE_UPFEAT) off[kInstr - 1] = (lane < kCK * kUpWRow / 4) ? lane * 16u : kOOB;
+        // tap fetches: LDS float d of the strip <- global float src(d), interleaving the two output channels
+        unsigned woff[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = h * 64 + lane;
+            {   // head: d = c*20 + tap*2 + co  <-  c*20 + co*10 + tap   (d%20 >= 18: zero pad)
+                const int c = d / kHeadWRow, r = d % kHeadWRow;
+                const bool ok = (MODE & MODE_HEAD) && (d < kCK * kHeadWRow) && (r < 18);
+                woff[h] = ok ? (unsigned)(c * kHeadWRow + (r & 1) * 10 + (r >> 1)) * 4u : kOOB;
+            }
+            {   // upfeat: d = c*32 + t*2 + co  <-  c*32 + co*16 + t
+                const int c = d / kUpWRow, r = d % kUpWRow;
+                const bool ok = (MODE & MODE_UPFEAT) && (d < kCK * kUpWRow);
+                woff[2 + h] = ok ? (unsigned)(c * kUpWRow + (r & 1) * 16 + (r >> 1)) * 4u : kOOB;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kRing - 1; ++k)
-            if (k < nchunks) issue<MODE>(xb, hw, uw, k, Cin, plane, smem + k * kBuf, off);
+            if (k < nchunks) issue<MODE>(xb, hw, uw, k, Cin, plane, smem + k * kBuf, off, woff);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            if (chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kInstr) : "memory");   // kRing == 3
+            if (chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kVmem) : "memory");   // kRing == 3
             else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // consumers may read slot chunk%3; they are done with (chunk-1)%3
             if (chunk + kRing - 1 < nchunks)
-                issue<MODE>(xb, hw, uw, chunk + kRing - 1, Cin, plane, smem + ((chunk + kRing - 1) % kRing) * kBuf, off);
+                issue<MODE>(xb, hw, uw, chunk + kRing - 1, Cin, plane, smem + ((chunk + kRing - 1) % kRing) * kBuf, off, woff);
         }
         return;
     }
 
-    float hacc[2][4];                   // HEAD:   [co][px]
-    float uacc[2][2][8];                // UPFEAT: [co][out row parity][out col 0..7] (8 output cols for 4 input px)
+    f32x2 hacc[4];                      // HEAD:   [px] -> (co0, co1)
+    f32x2 uacc[2][8];                   // UPFEAT: [out row parity][out col 0..7] -> (co0, co1)   (8 output cols for 4 input px)
 #pragma unroll
-    for (int co = 0; co < 2; ++co) {
+    for (int p = 0; p < 4; ++p) hacc[p] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < 4; ++p) hacc[co][p] = 0.f;
+    for (int py = 0; py < 2; ++py)
 #pragma unroll
-        for (int py = 0; py < 2; ++py)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) uacc[co][py][k] = 0.f;
-    }
+        for (int k = 0; k < 8; ++k) uacc[py][k] = f32x2{0.f, 0.f};
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __builtin_amdgcn_s_barrier();
@@ -157,42 +171,47 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
             }
             if constexpr (MODE & MODE_HEAD) {
                 const float4 *wq = reinterpret_cast<const float4 *>(cur + kHeadWOff + c * kHeadWRow);   // LDS broadcast
-                const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2], q3 = wq[3], q4 = wq[4];
-                const float wk[2][9] = {{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x},
-                                        {q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, q4.z}};
+                const float4 q0 = wq[0], q1 = wq[1], q2 = wq[2], q3 = wq[3];
+                const float2 q4 = *reinterpret_cast<const float2 *>(cur + kHeadWOff + c * kHeadWRow + 16);
+                const f32x2 wk[9] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}, {q2.x, q2.y},
+                                     {q2.z, q2.w}, {q3.x, q3.y}, {q3.z, q3.w}, {q4.x, q4.y}};          // [tap] -> (co0, co1)
 #pragma unroll
-                for (int co = 0; co < 2; ++co)
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                            for (int p = 0; p < 4; ++p) hacc[co][p] = fmaf(v[ky][p + kx], wk[co][ky * 3 + kx], hacc[co][p]);
+                        for (int p = 0; p < 4; ++p) {
+                            const float a = v[ky][p + kx];
+                            hacc[p] = __builtin_elementwise_fma(f32x2{a, a}, wk[ky * 3 + kx], hacc[p]);
+                        }
             }
             if constexpr (MODE & MODE_UPFEAT) {
                 // oy = 2*iy' - 1 + ky: out row 2*iy+py takes py=0: (iy-1,ky=3),(iy,ky=1); py=1: (iy,ky=2),(iy+1,ky=0)
                 // window row index a: iy-1+a ; window col index e: ix-1+e, pixel p sits at e = p+1
                 const float4 *wq = reinterpret_cast<const float4 *>(cur + kUpWOff + c * kUpWRow);       // LDS broadcast
+                f32x2 k[16];                                                                            // [ky*4+kx] -> (co0, co1)
 #pragma unroll
-                for (int co = 0; co < 2; ++co) {
-                    const float4 k0 = wq[co * 4 + 0], k1 = wq[co * 4 + 1], k2 = wq[co * 4 + 2], k3 = wq[co * 4 + 3];
-                    const float k[16] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w,
-                                         k2.x, k2.y, k2.z, k2.w, k3.x, k3.y, k3.z, k3.w};        // k[ky*4 + kx]
+                for (int j = 0; j < 8; ++j) {
+                    const float4 q = wq[j];
+                    k[2 * j] = f32x2{q.x, q.y};
+                    k[2 * j + 1] = f32x2{q.z, q.w};
+                }
 #pragma unroll
-                    for (int py = 0; py < 2; ++py) {
-                        const int kya = py ? 2 : 3, kyb = py ? 0 : 1;        // window rows a = py, py+1
+                for (int py = 0; py < 2; ++py) {
+                    const int kya = py ? 2 : 3, kyb = py ? 0 : 1;        // window rows a = py, py+1
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) {
+                    for (int p = 0; p < 4; ++p) {
 #pragma unroll
-                            for (int px = 0; px < 2; ++px) {
-                                const int kxa = px ? 2 : 3, kxb = px ? 0 : 1;    // window cols e = p+px, p+px+1
-                                float s = uacc[co][py][2 * p + px];
-                                s = fmaf(v[py][p + px], k[kya * 4 + kxa], s);
-                                s = fmaf(v[py][p + px + 1], k[kya * 4 + kxb], s);
-                                s = fmaf(v[py + 1][p + px], k[kyb * 4 + kxa], s);
-                                s = fmaf(v[py + 1][p + px + 1], k[kyb * 4 + kxb], s);
-                                uacc[co][py][2 * p + px] = s;
-                            }
+                        for (int px = 0; px < 2; ++px) {
+                            const int kxa = px ? 2 : 3, kxb = px ? 0 : 1;    // window cols e = p+px, p+px+1
+                            const float a0 = v[py][p + px], a1 = v[py][p + px + 1];
+                            const float b0 = v[py + 1][p + px], b1 = v[py + 1][p + px + 1];
+                            f32x2 s = uacc[py][2 * p + px];
+                            s = __builtin_elementwise_fma(f32x2{a0, a0}, k[kya * 4 + kxa], s);
+                            s = __builtin_elementwise_fma(f32x2{a1, a1}, k[kya * 4 + kxb], s);
+                            s = __builtin_elementwise_fma(f32x2{b0, b0}, k[kyb * 4 + kxa], s);
+                            s = __builtin_elementwise_fma(f32x2{b1, b1}, k[kyb * 4 + kxb], s);
+                            uacc[py][2 * p + px] = s;
                         }
                     }
                 }
@@ -209,7 +228,7 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
         for (int co = 0; co < 2; ++co) {
             const int64_t o = (int64_t)co * plane + (int64_t)oy * W + ox;
             const float bv = hbias[co];
-            float4 v = make_float4(hacc[co][0] + bv, hacc[co][1] + bv, hacc[co][2] + bv, hacc[co][3] + bv);
+            float4 v = make_float4(hacc[0][co] + bv, hacc[1][co] + bv, hacc[2][co] + bv, hacc[3][co] + bv);
             if (do_leaky) { v.x = leaky(v.x, slope); v.y = leaky(v.y, slope); v.z = leaky(v.z, slope); v.w = leaky(v.w, slope); }
             if (residual) {
                 const float4 rr = *reinterpret_cast<const float4 *>(residual + (int64_t)b * bsr + o);
@@ -226,10 +245,10 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 float *p = uy + (int64_t)b * bsuy + (int64_t)co * 4 * plane + (int64_t)(2 * oy + py) * Wo + 2 * ox;
-                *reinterpret_cast<float4 *>(p) = make_float4(uacc[co][py][0] + bv, uacc[co][py][1] + bv,
-                                                             uacc[co][py][2] + bv, uacc[co][py][3] + bv);
-                *reinterpret_cast<float4 *>(p + 4) = make_float4(uacc[co][py][4] + bv, uacc[co][py][5] + bv,
-                                                                 uacc[co][py][6] + bv, uacc[co][py][7] + bv);
+                *reinterpret_cast<float4 *>(p) = make_float4(uacc[py][0][co] + bv, uacc[py][1][co] + bv,
+                                                             uacc[py][2][co] + bv, uacc[py][3][co] + bv);
+                *reinterpret_cast<float4 *>(p + 4) = make_float4(uacc[py][4][co] + bv, uacc[py][5][co] + bv,
+                                                                 uacc[py][6][co] + bv, uacc[py][7][co] + bv);
             }
         }
     }
