@@ -221,7 +221,8 @@ def main():
             flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
             ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
             ach = flops / (ms * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "conv3x3_mfma_kernel<MT=4,NT=1,S=1,D=1,two-per-CU> (dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
+            result["roofline"] = {"kernel": "conv3x3_mfma_kernel<4, 1, 1, 1, 1, 0> = <MT,NT,stride,dilation,two-per-CU,split-K> "
+                                            "(dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
                                   "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                                   "traffic": pmc_traffic("conv3x3_mfma_dc_conv1_b16", B == 16 and (H, W) == (448, 1024)),
@@ -234,7 +235,7 @@ def main():
         ms = event_time_ms(lambda: ops.correlation(ar[:, off:off + c2], plan.warped[2], 4, 1, 4, 1, 1, 1.0,
                                                    leaky_slope=0.1, out=ar[:, 448:529]), 20, stream)
         gbs = bytes_corr / (ms * 1e-3) / 1e9
-        result["roofline_corr"] = {"kernel": "corr81_kernel<f32> (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena write)" % (w2, h2, B),
+        result["roofline_corr"] = {"kernel": "corr81_dma_kernel (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena write)" % (w2, h2, B),
                                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
                                    "traffic": pmc_traffic("corr81_level2_b16", B == 16 and (H, W) == (448, 1024)),

@@ -48,9 +48,9 @@ __device__ __forceinline__ void *uniform_ptr(const void *p) {
     return reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
 }
 
-template <int MT, int NT, int S, int D, int TWO>
+template <int MT, int NT, int S, int D, int TWO, int CKO = 0>
 struct Geom {
-    static constexpr int kCK = TWO ? 4 : 8;                         // input channels per chunk
+    static constexpr int kCK = CKO ? CKO : (TWO ? 4 : 8);           // input channels per chunk
     static constexpr int kWPS = TWO ? 2 : 1;                        // waves per SIMD the register budget must allow
     static constexpr int kTileH = 4 * NT;
     static constexpr bool kRowSep = (D >= 16);                      // stage the three ky row-sets separately
@@ -240,6 +240,123 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     }
 }
 
+// ---- Cout <= 16 (conv1aa / conv1b: 16 -> 16 at half resolution) -----------------------------------------------
+// With the 32x32x2 MFMA half of the 32 cout rows would be padding.  v_mfma_f32_16x16x4_f32 has the same FLOP rate
+// on a 16 cout x 16 pixel x 4 channel step (A[l&15][k=l>>4], B[k=l>>4][l&15], D row = 4*(l>>4)+reg, col = l&15), so
+// the same LDS image (stride 1, dilation 1 geometry of Geom<1,NT,1,1,..>) is consumed with the four lane quarters
+// on four consecutive channels of one tap and two MFMAs per 32-pixel row segment: no wasted rows.
+// Measured on conv1aa (16 -> 16 @224x512, 32 images): 338 us with the 32x32x2 kernel, 229 us here with 16-row tiles
+// and 4-channel chunks; staging the whole Cin = 16 as one chunk (no pipelining inside a workgroup) is slower
+// (275-292 us), see profiles/r01_conv_notes.md.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int CKT>
+__global__ void __launch_bounds__(kThreads, 2)
+conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+                      const float *__restrict__ residual, float *__restrict__ y,
+                      int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                      int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky) {
+    using G = Geom<1, NT, 1, 1, 1, CKT>;
+    constexpr int CK = G::kCK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int acol = lane & 15;         // A: cout row / B, D: pixel column inside a 16-wide half
+    const int kg = lane >> 4;           // A, B: channel inside the group of 4 / D: cout rows 4*kg .. 4*kg+3
+
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int ox0 = tx * kTileW;
+    const int oy0 = ty * G::kTileH;
+    const int plane = H * W;
+
+    unsigned in_off[G::kInSlots];
+#pragma unroll
+    for (int j = 0; j < G::kInSlots; ++j) {
+        const int i = j * kThreads + tid;
+        const int c = i / G::kCH;
+        const int rem = i % G::kCH;
+        const int iy = oy0 - 1 + rem / G::kInW;
+        const int ix = ox0 - 1 + rem % G::kInW;
+        const bool ok = (i < G::kInElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+        in_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+    }
+    unsigned w_off[G::kWSlots];
+#pragma unroll
+    for (int j = 0; j < G::kWSlots; ++j) {
+        const int p = j * kThreads + tid;
+        const int row = p / (G::kCoutT / 4);
+        const int q = p % (G::kCoutT / 4);
+        w_off[j] = (p < G::kWPieces) ? (unsigned)(row * CoutP + q * 4) * 4u : kOOB;
+    }
+
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float bv = bias[min(kg * 4 + j, Cout - 1)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { acc[nt][0][j] = bv; acc[nt][1][j] = bv; }
+    }
+
+    const float *xb = x + (int64_t)b * bsx;
+    const int nchunks = (Cin + CK - 1) / CK;
+    const int64_t wchunk = (int64_t)CK * 9 * CoutP;
+    const unsigned wbytes = (unsigned)wchunk * 4u;
+
+    issue_chunk<G>(xb, wp, 0, Cin, plane, wchunk, wbytes, wave, smem, in_off, w_off);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        float *cur = smem + (chunk & 1) * G::kBufFloats;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // see conv3x3_mfma_kernel
+        __syncthreads();
+        if (chunk + 1 < nchunks)
+            issue_chunk<G>(xb, wp, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
+                           in_off, w_off);
+        const float *rd_in = cur + kg * G::kCH + (wave * NT) * G::kInW + acol;
+        const float *rd_w = cur + G::kInRegion + kg * 9 * G::kCoutT + acol;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int kq = 0; kq < CK / 4; ++kq) {
+                const float a = rd_w[(kq * 4 * 9 + tap) * G::kCoutT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float *p = rd_in + kq * 4 * G::kCH + (nt + ky) * G::kInW + kx;
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[0], acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[16], acc[nt][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int64_t oplane = (int64_t)H * W;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int oy = oy0 + wave * NT + nt;
+        if (oy >= H) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ox = ox0 + 16 * h + acol;
+            if (ox >= W) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = kg * 4 + j;
+                if (co >= Cout) continue;
+                float v = acc[nt][h][j];
+                if (do_leaky) v = leaky(v, slope);
+                const int64_t off = (int64_t)co * oplane + (int64_t)oy * W + ox;
+                if (residual) v += residual[(int64_t)b * bsr + off];
+                y[(int64_t)b * bsy + off] = v;
+            }
+        }
+    }
+}
+
 }  // namespace (anonymous)
 
 struct ConvArgs {
@@ -316,6 +433,47 @@ int launch_split(const ConvArgs &a) {
                        a.stream, a.x, a.wp, a.bias, (const float *)nullptr, a.partial, a.Cin, a.H, a.W, a.Cout, a.CoutP,
                        a.Ho, a.Wo, tiles_x, tiles_y, a.bsx, bsp, (int64_t)0, 0.f, 0, a.cps, (int64_t)a.B * bsp);
     return pwc::check_launch("conv3x3_mfma_kernel<split>");
+}
+
+// Cout <= 16, stride 1, dilation 1: the 16x16x4 kernel.  NT (tile rows / 4) from PWC_CONV16_TILE or the rule below.
+struct TileChoice16 { int nt; };
+
+template <int NT, int CKT>
+int launch16(const ConvArgs &a) {
+    using G = Geom<1, NT, 1, 1, 1, CKT>;
+    static_assert(G::kSmemBytes <= 160 * 1024, "tile does not exist");
+    const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+    const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
+    const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: grid too large");
+    auto kern = conv3x3_mfma16_kernel<NT, CKT>;
+    static pwc::LdsAttrOnce attr;
+    if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmemBytes, "pwc_conv2d_fwd"))
+        return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), G::kSmemBytes, a.stream,
+                       a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, tiles_x, tiles_y,
+                       a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky);
+    return pwc::check_launch("conv3x3_mfma16_kernel");
+}
+
+inline int dispatch16(const ConvArgs &a) {
+    static const TileChoice16 forced = [] {
+        TileChoice16 f{0};
+        const char *e = getenv("PWC_CONV16_TILE");
+        if (e) sscanf(e, "%d", &f.nt);
+        return f;
+    }();
+    TileChoice16 t = forced;
+    if (t.nt == 0) {
+        // rows per tile: 4 while the grid is small, 16 once there are plenty of tiles (measured: 248 / 234 / 229 us
+        // for 4 / 8 / 16 rows on conv1aa at batch 16; 17.9 us vs 23 us for 4 vs 8 rows at batch 1)
+        const int64_t blocks1 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 3) / 4);
+        t.nt = blocks1 <= 2048 ? 1 : (blocks1 <= 8192 ? 2 : 4);
+    }
+    if (t.nt == 1) return launch16<1, 4>(a);
+    if (t.nt == 2) return launch16<2, 4>(a);
+    if (t.nt == 4) return launch16<4, 4>(a);
+    PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: PWC_CONV16_TILE must be 1, 2 or 4");
 }
 
 // (MT, NT, TWO) choice by a cost model fitted to measurements on MI355X (time in units of one MFMA

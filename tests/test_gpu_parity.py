@@ -223,6 +223,10 @@ CONV_CASES = [
     # (B, Cin, Cout, H, W, stride, dilation)
     (2, 3, 16, 64, 64, 2, 1),
     (1, 16, 16, 32, 96, 1, 1),
+    (2, 21, 9, 20, 45, 1, 1),          # Cout <= 16: 16x16x4 MFMA kernel, ragged Cin / Cout / edges
+    (3, 16, 16, 120, 200, 1, 1),       # ... 4-row tiles
+    (4, 16, 16, 224, 512, 1, 1),       # ... 8-row tiles (conv1aa geometry)
+    (10, 16, 16, 224, 500, 1, 1),      # ... 16-row tiles, ragged right edge
     (2, 32, 64, 16, 32, 2, 1),
     (1, 128, 196, 14, 32, 2, 1),
     (1, 196, 196, 7, 16, 1, 1),
