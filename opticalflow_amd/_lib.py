@@ -10,7 +10,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpwc_hip.so")
+# PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
+LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
 ABI_VERSION = 2
 PWC_F32, PWC_F16 = 0, 1

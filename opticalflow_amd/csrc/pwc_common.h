@@ -79,6 +79,11 @@ __device__ __forceinline__ void dma_b128(v4i32 rsrc, unsigned lds_base, unsigned
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :: "s"(lds_base), "v"(voffset), "s"(rsrc) : "memory");
 }
+// same with the non-temporal cache policy (streamed-once bytes)
+__device__ __forceinline__ void dma_b128_nt(v4i32 rsrc, unsigned lds_base, unsigned voffset) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ void dma_b32(v4i32 rsrc, unsigned lds_base, unsigned voffset) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
                  :: "s"(lds_base), "v"(voffset), "s"(rsrc) : "memory");

@@ -24,6 +24,20 @@
 // other than PWCDCNet.
 #include "pwc_common.h"
 
+// Cache policy (profiles/r01_corr_ablation.md): the 81-channel output is written once and not read again by this
+// kernel -> non-temporal stores (64.8 -> 59.8 us at level 2, batch 16; whole forward unchanged).  The inputs are NOT
+// streamed non-temporally: the 2.5x halo re-reads must hit in L2 (nt loads: 78 us).  -DPWC_CORR_NT_LOAD /
+// -DPWC_CORR_TEMPORAL_STORE rebuild the other variants.
+#ifndef PWC_CORR_TEMPORAL_STORE
+#define PWC_CORR_NT_STORE 1
+#endif
+#ifdef PWC_CORR_NT_LOAD
+#define PWC_CORR_DMA pwc::dma_b128_nt
+#else
+#define PWC_CORR_DMA pwc::dma_b128
+#endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 namespace {
 
 using pwc::from_f32;
@@ -265,9 +279,9 @@ __device__ __forceinline__ void corr_issue(const float *p1, const float *p2, int
     const pwc::v4i32 r1 = pwc::make_rsrc(p1 + (int64_t)c0 * plane, nbytes);
     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
 #pragma unroll
-    for (int k = 0; k < kS2Instr; ++k) pwc::dma_b128(r2, base + k * 1024, off[k]);
+    for (int k = 0; k < kS2Instr; ++k) PWC_CORR_DMA(r2, base + k * 1024, off[k]);
 #pragma unroll
-    for (int k = kS2Instr; k < kDmaInstr; ++k) pwc::dma_b128(r1, base + k * 1024, off[k]);
+    for (int k = kS2Instr; k < kDmaInstr; ++k) PWC_CORR_DMA(r1, base + k * 1024, off[k]);
 }
 
 __global__ void __launch_bounds__(kThreadsDma)
@@ -372,7 +386,11 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
                         q *= scale;
                         v[p] = do_leaky ? leaky(q, slope) : q;
                     }
+#ifdef PWC_CORR_NT_STORE
+                    __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v *>(po + (int64_t)dx * plane));
+#else
                     *reinterpret_cast<float4 *>(po + (int64_t)dx * plane) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
                 }
             }
 #pragma unroll

@@ -69,8 +69,9 @@ def postprocess(flow2: torch.Tensor, h: int, w: int) -> torch.Tensor:
     h_, w_ = padded_size(h, w)
     flo = flow2[:1] * 20.0
     flo = _resize_bilinear(flo, h, w)
-    scale = torch.tensor([w / float(w_), h / float(h_)], dtype=flo.dtype, device=flo.device).view(1, 2, 1, 1)
-    return (flo * scale)[0].permute(1, 2, 0).contiguous()
+    flo[:, 0].mul_(w / float(w_))          # python scalars: a per-call device tensor would be a blocking pageable upload
+    flo[:, 1].mul_(h / float(h_))
+    return flo[0].permute(1, 2, 0).contiguous()
 
 
 @torch.no_grad()

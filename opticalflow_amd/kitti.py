@@ -49,14 +49,28 @@ def flow_resize(flow: torch.Tensor, new_h: int, new_w: int) -> torch.Tensor:
     if (h, w) == (new_h, new_w):
         return flow
     out = F.interpolate(flow, size=(new_h, new_w), mode="bilinear", align_corners=True)
-    scale = torch.tensor([new_w / w, new_h / h], dtype=out.dtype, device=out.device).view(1, 2, 1, 1)
-    return out * scale
+    # python scalars, not a device tensor built per call: a pageable H2D copy here stalls the stream (measured
+    # 20 ms per pair in the KITTI loop, tools/bench_kitti.py)
+    out[:, 0].mul_(new_w / w)
+    out[:, 1].mul_(new_h / h)
+    return out
+
+
+_NORM_CACHE = {}
+
+
+def _norm_constants(device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ImageNet mean / std as [1,3,1,1] tensors, uploaded once per device."""
+    key = str(device)
+    if key not in _NORM_CACHE:
+        _NORM_CACHE[key] = (torch.tensor(IMAGENET_MEAN, device=device).view(1, 3, 1, 1),
+                            torch.tensor(IMAGENET_STD, device=device).view(1, 3, 1, 1))
+    return _NORM_CACHE[key]
 
 
 def normalize_pair(img1_u8: torch.Tensor, img2_u8: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """[H,W,3] uint8 RGB -> [1,3,H,W] float, ToTensor + ImageNet normalisation (on the tensors' device)."""
-    mean = torch.tensor(IMAGENET_MEAN, device=img1_u8.device).view(1, 3, 1, 1)
-    std = torch.tensor(IMAGENET_STD, device=img1_u8.device).view(1, 3, 1, 1)
+    mean, std = _norm_constants(img1_u8.device)
     outs = []
     for im in (img1_u8, img2_u8):
         t = im[..., :3].permute(2, 0, 1).unsqueeze(0).to(torch.float32) / 255.0
@@ -198,17 +212,24 @@ class PairStream:
         self.device = device
         self.copy_stream = torch.cuda.Stream(device=device)
         self.slots = [None, None]          # pinned host staging, allocated on first use per shape
+        self.uploaded = [None, None]       # event of the last upload that read each staging buffer
 
     def _stage(self, slot: int, pair):
         a, b = pair
-        host = torch.stack((a[..., :3], b[..., :3]), 0).contiguous()          # [2,H,W,3] uint8
-        if self.slots[slot] is None or self.slots[slot].shape != host.shape:
-            self.slots[slot] = torch.empty(host.shape, dtype=torch.uint8).pin_memory()
-        self.slots[slot].copy_(host)
+        shape = (2,) + tuple(a.shape[:2]) + (3,)                               # [2,H,W,3] uint8
+        if tuple(b.shape[:2]) != tuple(a.shape[:2]) or a.dtype != torch.uint8 or b.dtype != torch.uint8:
+            raise ValueError("a pair must be two uint8 [H,W,>=3] images of the same size")
+        if self.slots[slot] is None or tuple(self.slots[slot].shape) != shape:
+            self.slots[slot] = torch.empty(shape, dtype=torch.uint8).pin_memory()
+        elif self.uploaded[slot] is not None:
+            self.uploaded[slot].synchronize()      # the DMA that last read this buffer must be done before it is rewritten
+        self.slots[slot][0].copy_(a[..., :3])      # straight into pinned memory (an intermediate torch.stack cost 5 ms/pair)
+        self.slots[slot][1].copy_(b[..., :3])
         with torch.cuda.stream(self.copy_stream):
             dev = self.slots[slot].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
+        self.uploaded[slot] = ev
         return dev, ev
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
