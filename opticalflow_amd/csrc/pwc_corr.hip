@@ -26,7 +26,7 @@
 
 // Cache policy (profiles/r01_corr_ablation.md): the 81-channel output is written once and not read again by this
 // kernel -> non-temporal stores (64.8 -> 59.8 us at level 2, batch 16; whole forward unchanged).  The inputs are NOT
-// streamed non-temporally: the 2.5x halo re-reads must hit in L2 (nt loads: 78 us).  -DPWC_CORR_NT_LOAD /
+// streamed non-temporally: the 2.5x halo re-reads must hit in L2 (nt loads: 78 us; nt on in1 only: +8 %).  -DPWC_CORR_NT_LOAD /
 // -DPWC_CORR_TEMPORAL_STORE rebuild the other variants.
 #ifndef PWC_CORR_TEMPORAL_STORE
 #define PWC_CORR_NT_STORE 1
