@@ -28,6 +28,13 @@
 
 #include "pwc_common.h"
 
+// output store policy of the MFMA kernels: -DPWC_CONV_NT_STORE streams the activations past L2 (experiment)
+#ifdef PWC_CONV_NT_STORE
+#define PWC_CONV_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define PWC_CONV_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace pwc_conv {
 
 using pwc::leaky;
@@ -233,7 +240,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
                 } else {
                     if (do_leaky) v = leaky(v, slope);
                     if (residual) v += residual[(int64_t)b * bsr + off];
-                    y[(int64_t)b * bsy + off] = v;
+                    PWC_CONV_STORE(y + (int64_t)b * bsy + off, v);
                 }
             }
         }
@@ -351,7 +358,7 @@ conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp,
                 if (do_leaky) v = leaky(v, slope);
                 const int64_t off = (int64_t)co * oplane + (int64_t)oy * W + ox;
                 if (residual) v += residual[(int64_t)b * bsr + off];
-                y[(int64_t)b * bsy + off] = v;
+                PWC_CONV_STORE(y + (int64_t)b * bsy + off, v);
             }
         }
     }

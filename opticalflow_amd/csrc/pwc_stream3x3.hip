@@ -22,6 +22,12 @@
 // use other kernels otherwise.
 #include "pwc_common.h"
 
+#ifdef PWC_STREAM_NT_LOAD          // experiment: stream the arena with the non-temporal policy
+#define PWC_STREAM_DMA pwc::dma_b128_nt
+#else
+#define PWC_STREAM_DMA pwc::dma_b128
+#endif
+
 namespace {
 
 using pwc::leaky;
@@ -63,7 +69,7 @@ __device__ __forceinline__ void issue(const float *xb, const float *hw, const fl
     const pwc::v4i32 r = pwc::make_rsrc(xb + (int64_t)c0 * plane, cvalid * plane * 4);
     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
 #pragma unroll
-    for (int i = 0; i < kInstr - 2; ++i) pwc::dma_b128(r, base + i * 1024, off[i]);
+    for (int i = 0; i < kInstr - 2; ++i) PWC_STREAM_DMA(r, base + i * 1024, off[i]);
     const pwc::v4i32 rh = (MODE & MODE_HEAD) ? pwc::make_rsrc(hw + (int64_t)c0 * kHeadWRow, cvalid * kHeadWRow * 4) : r;
     pwc::dma_b32(rh, base + (kInstr - 2) * 1024, woff[0]);
     pwc::dma_b32(rh, base + (kInstr - 2) * 1024 + 256, woff[1]);
