@@ -128,3 +128,25 @@ def test_model_infer_and_stream_on_gpu(gpu_device):
     gt = got[0][0].permute(1, 2, 0).numpy()
     epe, fl, rows = kitti.evaluate_pairs(net, [(s[0], s[1], gt, np.ones((100, 150), bool)) for s in samples[:1]], gpu_device)
     assert epe < 1e-4 and fl == 0.0 and len(rows) == 1
+
+
+@pytest.mark.gpu
+def test_graphed_infer_equals_eager_pipeline(gpu_device):
+    """kitti.GraphedInfer (normalise + pad + forward + unpad + resize as one HIP graph) returns exactly what the eager
+    model_infer does, pair after pair, fed by PairStream(raw=True)."""
+    from opticalflow_amd import PWCDCNet, kitti
+    from opticalflow_amd.weights import synthetic_state_dict
+    net = PWCDCNet().to(gpu_device).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=2, gain=0.85, bias_std=0.02))
+    g = torch.Generator().manual_seed(12)
+    samples = [(torch.randint(0, 256, (100, 150, 3), generator=g, dtype=torch.uint8),
+                torch.randint(0, 256, (100, 150, 3), generator=g, dtype=torch.uint8)) for _ in range(3)]
+    ref = [kitti.model_infer(net, a, b).cpu() for a, b in kitti.PairStream(samples, gpu_device)]
+    pipe = kitti.GraphedInfer(net, 100, 150, gpu_device)
+    got = [pipe(u8).cpu() for u8 in kitti.PairStream(samples, gpu_device, raw=True)]
+    assert net.use_graph is False                              # restored after capture
+    for r, o in zip(ref, got):
+        assert o.shape == r.shape == (1, 2, 100, 150)
+        assert torch.equal(o, r)
+    with pytest.raises(ValueError):
+        pipe(torch.zeros((2, 64, 64, 3), dtype=torch.uint8, device=gpu_device))
