@@ -234,7 +234,10 @@ constexpr int kBufFloats = kS2Floats + kS1Floats;         // 3840 floats = 15 Ki
 constexpr unsigned kOOBv = 0x80000000u;
 constexpr int kLoaderWave = kND;                          // wave 9 (a second loader wave measured slower: 72 vs 65 us)
 constexpr int kThreadsDma = 64 * (kND + 1);               // 640
-constexpr int kPersistentPerCU = 2;
+#ifndef PWC_CORR_PER_CU
+#define PWC_CORR_PER_CU 2
+#endif
+constexpr int kPersistentPerCU = PWC_CORR_PER_CU;
 
 struct TileXY { int b, x0, y0; };
 
@@ -301,6 +304,10 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
 
     if (wave == kLoaderWave) {
         // ================= producer: keeps two chunks in flight ahead of the consumers =====================
+        // the ring must never wait for issue slots behind nine fma waves (57.5 -> 56.5 us, -DPWC_CORR_NO_PRIO to compare)
+#ifndef PWC_CORR_NO_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         int is_tile = blockIdx.x, is_chunk = 0, is_step = 0;
         unsigned off[kDmaInstr];
         const float *ip1 = nullptr, *ip2 = nullptr;

@@ -13,6 +13,9 @@ def short(n):
     m = re.search(r"conv3x3_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", n)
     if m:
         return "mfma<MT%s,NT%s,S%s,D%s,two%s>" % m.groups()[:5] + ("+splitK" if m.group(6) == "1" else "")
+    m = re.search(r"conv3x3_mfma16_kernel<(\d+), (\d+)>", n)
+    if m:
+        return "mfma16<NT%s,CK%s>" % m.groups()
     for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "splitk_reduce", "warp_kernel", "copyBuffer", "elementwise", "pack3x3"):
         if k in n:
             return k
