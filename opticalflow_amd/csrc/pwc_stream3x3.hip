@@ -107,6 +107,9 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
 
     if (wave == 4) {
         // ================= producer wave: runs the ring, two chunks ahead of the consumers ==================
+#ifndef PWC_STREAM_NO_PRIO
+        __builtin_amdgcn_s_setprio(3);     // as in the correlation kernel: the ring's issue slots come first
+#endif
         unsigned off[kInstr - 2];
 #pragma unroll
         for (int i = 0; i < kInstr - 2; ++i) {
