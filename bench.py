@@ -156,6 +156,12 @@ def main():
     bcast_bytes = broadcast_parameters(net, src=0) if world > 1 else 0
 
     x = torch.rand(B, 6, H, W, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)
+    if not args.no_graph:
+        # the pairs live in the captured forward's own input buffer (what an ingest stage would write into), so
+        # no device-to-device staging copy is part of a step
+        xin = net.graph_input(B, H, W, dev)
+        xin.copy_(x)
+        x = xin
     counts = [B] * world
 
     def step():

@@ -174,9 +174,28 @@ class PWCDCNet(nn.Module):
             entry = (graph, static_in)
             self._graphs[key] = entry
         graph, static_in = entry
-        static_in.copy_(x)
+        if x.data_ptr() != static_in.data_ptr():        # a caller that fills graph_input() in place skips this copy
+            static_in.copy_(x)
         graph.replay()
         return plan.flow_out
+
+    @torch.no_grad()
+    def graph_input(self, batch: int, height: int, width: int, device=None) -> torch.Tensor:
+        """The captured forward's own input buffer [B,6,H,W] (requires ``use_graph``): write the next pairs into it
+        (e.g. as the destination of the H2D copy or of a decoder) and pass it to ``forward`` -- the 11 MB-per-pair
+        device-to-device staging copy of a foreign input tensor is then skipped."""
+        if not self.use_graph:
+            raise RuntimeError("graph_input() needs use_graph=True")
+        device = device or next(self.parameters()).device
+        x = torch.zeros((batch, 6, height, width), device=device)
+        key = self._key(x)
+        if key not in self._graphs:
+            training, self.training = self.training, False
+            try:
+                self.forward(x)
+            finally:
+                self.training = training
+        return self._graphs[key][1]
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_plans()

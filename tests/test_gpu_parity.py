@@ -431,6 +431,14 @@ def test_forward_training_tuple_and_graph(dev):
     b = net(x * 0.5)
     c = net(x)
     assert torch.equal(a, eager) and torch.equal(a, c) and not torch.equal(a, b)
+    # filling the captured forward's own input buffer in place skips the staging copy and gives the same flow
+    xin = net.graph_input(x.shape[0], x.shape[2], x.shape[3])
+    assert xin.shape == x.shape and xin.data_ptr() != x.data_ptr()
+    xin.copy_(x * 0.5)
+    assert torch.equal(net(xin), b)
+    net.use_graph = False
+    with pytest.raises(RuntimeError):
+        net.graph_input(1, 64, 64)
 
 
 def test_forward_rejects_bad_inputs(dev):
