@@ -24,6 +24,8 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+# dmabuf IPC for RCCL / cross-process device memory on this driver stack (must be set before the HIP runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
@@ -276,9 +278,15 @@ def main():
                     dt = time.perf_counter() - t0
                     if dt >= args.cpu_seconds or n >= 50:
                         break
+            cpu_model = "unknown CPU"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+            except (OSError, StopIteration):
+                pass
             result["cpu_baseline"] = {"value": round(n / dt, 3), "unit": "image-pairs/s", "cores": cores, "kind": "port",
-                                      "sample": "%d forwards of 1x6x%dx%d fp32 by oracle/pwc_oracle.py (torch CPU, %d threads) after 1 warm-up"
-                                                % (n, H, W, cores)}
+                                      "sample": "%d forwards of 1x6x%dx%d fp32 by oracle/pwc_oracle.py (torch CPU, %d threads on %s) "
+                                                "after 1 warm-up" % (n, H, W, cores, cpu_model)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
