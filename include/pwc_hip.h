@@ -115,6 +115,22 @@ int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, const void *
 /* Bytes of workspace the split-K route of this layer needs (0: the layer never splits; <0: bad shape). */
 int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation);
 
+/* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------
+ * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch
+ * stride (in halves, multiple of 8) is free, so a tensor may be a channel-group slice of an arena.  fp32
+ * accumulation on v_mfma_f32_32x32x16_f16; bias fp32; optional LeakyReLU; output rounded to half.
+ * Same operator as pwc_conv2d_fwd (nn.Conv2d 3x3 + LeakyReLU, PWCNet.py:26-33); stride 1 with dilation 1,2,4 and
+ * stride 2 with dilation 1 so far (PWC_EUNSUPPORTED otherwise; no residual). */
+int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout);
+/* w: [Cout,Cin,3,3] f32 (nn.Conv2d layout, device) -> wp: packed halves [Cg/2][tap][2][CoutP][8]. */
+int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream);
+int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
+                       int B, int Cin, int H, int W, int Cout, int stride, int dilation,
+                       unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream);
+/* layout conversions at the edges of an fp16 pipeline: NCHW f32 <-> c8 f16 (batch strides in elements) */
+int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
+int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
+
 /* ConvTranspose2d(kernel 4, stride 2, padding 1) + bias.  x:[B,Cin,H,W], w:[Cin,Cout,4,4] (nn layout),
  * y:[B,Cout,2H,2W]. */
 int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bias, void *y,

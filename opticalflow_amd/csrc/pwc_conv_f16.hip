@@ -1,0 +1,364 @@
+// fp16 3x3 convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulation) -- the first piece of
+// the fp16 path (BASELINE configs 3-4).  Replaces nn.Conv2d(3x3) + LeakyReLU(0.1) (reference models/PWCNet.py:26-33)
+// for half-precision activations.
+//
+// Activation layout: channel-blocked  [B][Cg = ceil(C/8)][H][W][8] halves  ("c8"), so that the 8 consecutive k a lane
+// feeds to one MFMA operand are ONE 16-byte LDS read and one pixel is one 16-byte LDS-DMA piece (no alignment cases:
+// halo, zero padding and ragged edges are per-piece range checks).  Channels past C inside the last group are zero
+// and are written as zero.  Only the batch stride is free, so a tensor may be a channel-group slice of an arena.
+//
+// GEMM view, per (tap, pair of channel groups): D[cout 32][pixel 32] += A[cout][k 16] * B[k 16][pixel], k = 8*kh + j
+//   <-> channel 8*(2*cgp + kh) + j;  lane l: row/col = l & 31, kh = l >> 5.
+//   packed filters [cgp][tap][kh][CoutP][8]  -> A fragment = one ds_read_b128, 32 lanes x 16 B contiguous
+//   staged input   [kh][row][col][8]         -> B fragment = one ds_read_b128, 32 lanes x 16 B contiguous
+// Workgroup = 4 MFMA waves + 1 loader wave (the fp32 kernels showed that a wave cannot issue LDS-DMA and MFMA
+// back to back; here the bytes per MFMA cycle are 8x higher).  The loader runs a 3-slot ring of 16-channel chunks
+// (input halo tile + filter slab) under a counted vmcnt, one barrier per chunk.  Tile = (8 rows x 32 cols) x 32*MT couts.
+// Epilogue: bias (fp32), LeakyReLU, round to half, 8-byte stores that interleave to 512 contiguous bytes per wave.
+#include <stdlib.h>
+
+#include "pwc_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBlock = 320;          // waves 0..3: MFMA, wave 4: loader
+constexpr int kRing = 3;
+constexpr int kTileW = 32;
+constexpr int kNT = 2;               // rows per wave -> 8-row tiles
+constexpr unsigned kOOB = 0x80000000u;
+static_assert(kRing == 3, "the loader's counted wait assumes exactly one younger chunk in flight");
+
+template <int MT, int S, int D>
+struct G16 {
+    static constexpr int kTileH = 4 * kNT;
+    static constexpr int kInH = (kTileH - 1) * S + 2 * D + 1;
+    static constexpr int kInW = (kTileW - 1) * S + 2 * D + 1;
+    static constexpr int kInPieces = 2 * kInH * kInW;             // [kh][row][col] 16-byte pieces per chunk
+    static constexpr int kInInstr = (kInPieces + 63) / 64;
+    static constexpr int kCoutT = 32 * MT;
+    static constexpr int kWPieces = 18 * kCoutT;                   // [tap][kh][cout]
+    static constexpr int kWInstr = (kWPieces + 63) / 64;
+    static constexpr int kInstr = kInInstr + kWInstr;              // LDS-DMA instructions per chunk (1 KiB each)
+    static constexpr int kWOffBytes = kInInstr * 1024;
+    static constexpr int kSlotBytes = kInstr * 1024;
+    static constexpr int kSmem = kRing * kSlotBytes;
+    static constexpr bool kValid = kSmem <= 160 * 1024;
+};
+
+// loader wave: start the LDS-DMA of one 16-channel chunk (input halo tile, then the filter slab) into its ring slot
+template <class G>
+__device__ __forceinline__ void issue_f16(const _Float16 *xb, const _Float16 *wp, int chunk, int Cg, int plane, int CoutP,
+                                          unsigned char *smem, const unsigned *off) {
+    const int cgv = min(2, Cg - 2 * chunk);               // ragged last pair: kh = 1 is range-checked to zero
+    const pwc::v4i32 rin = pwc::make_rsrc(xb + (int64_t)chunk * 2 * plane * 8, cgv * plane * 16);
+    const pwc::v4i32 rw = pwc::make_rsrc(wp + (int64_t)chunk * 18 * CoutP * 8, 18 * CoutP * 16);
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(smem + (chunk % kRing) * G::kSlotBytes));
+#pragma unroll
+    for (int i = 0; i < G::kInInstr; ++i) pwc::dma_b128(rin, base + i * 1024, off[i]);
+#pragma unroll
+    for (int i = 0; i < G::kWInstr; ++i) pwc::dma_b128(rw, base + G::kWOffBytes + i * 1024, off[G::kInInstr + i]);
+}
+
+template <int MT, int S, int D>
+__global__ void __launch_bounds__(kBlock)
+conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp, const float *__restrict__ bias,
+                   _Float16 *__restrict__ y, int Cg, int H, int W, int Cout, int CoutP, int Ho, int Wo,
+                   int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int do_leaky) {
+    using G = G16<MT, S, D>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int g = blockIdx.y;
+    const int ox0 = tx * kTileW;
+    const int oy0 = ty * G::kTileH;
+    const int plane = H * W;
+    const int nchunks = (Cg + 1) / 2;
+    const _Float16 *xb = x + (int64_t)b * bsx;
+
+    if (wave == 4) {
+        // ================= loader wave =====================================================================
+        __builtin_amdgcn_s_setprio(3);
+        unsigned off[G::kInstr];
+#pragma unroll
+        for (int i = 0; i < G::kInInstr; ++i) {
+            const int p = i * 64 + lane;
+            const int kh = p / (G::kInH * G::kInW);
+            const int rem = p % (G::kInH * G::kInW);
+            const int iy = oy0 * S - D + rem / G::kInW;
+            const int ix = ox0 * S - D + rem % G::kInW;
+            const bool ok = (p < G::kInPieces) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+            off[i] = ok ? (unsigned)(kh * plane + iy * W + ix) * 16u : kOOB;
+        }
+#pragma unroll
+        for (int i = 0; i < G::kWInstr; ++i) {
+            const int q = i * 64 + lane;
+            const int row = q / G::kCoutT;                    // tap*2 + kh
+            const int co = g * G::kCoutT + q % G::kCoutT;
+            off[G::kInInstr + i] = (q < G::kWPieces && co < CoutP) ? (unsigned)(row * CoutP + co) * 16u : kOOB;
+        }
+        issue_f16<G>(xb, wp, 0, Cg, plane, CoutP, smem, off);
+        if (nchunks > 1) issue_f16<G>(xb, wp, 1, Cg, plane, CoutP, smem, off);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::kInstr) : "memory");
+            else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // consumers may read slot chunk%3; they are done with (chunk-1)%3
+            if (chunk + 2 < nchunks) issue_f16<G>(xb, wp, chunk + 2, Cg, plane, CoutP, smem, off);
+        }
+        return;
+    }
+
+    // ================= MFMA waves: wave w owns rows 2w, 2w+1 of the tile ======================================
+    const int col = lane & 31;
+    const int kh = lane >> 5;
+    f32x16 acc[MT][kNT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            const float bv = bias[min(co, Cout - 1)];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) acc[mt][nt][j] = bv;
+        }
+    }
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char *cur = smem + (chunk % kRing) * G::kSlotBytes;
+        const h8 *in = reinterpret_cast<const h8 *>(cur) + (kh * G::kInH + wave * kNT * S) * G::kInW + col * S;
+        const h8 *ws = reinterpret_cast<const h8 *>(cur + G::kWOffBytes) + kh * G::kCoutT + col;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            h8 a[MT], bv[kNT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = ws[tap * 2 * G::kCoutT + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) bv[nt] = in[(nt * S + ky * D) * G::kInW + kx * D];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS reads retired before the slot can be refilled
+    }
+
+    // ---- epilogue: register quad q of accumulator tile mt = channels 4*kh .. 4*kh+3 of output group (..)/8 + q ------
+    const int ox = ox0 + col;
+    const int64_t oplane = (int64_t)Ho * Wo;
+    const int cg_out = (Cout + 7) / 8;
+#pragma unroll
+    for (int nt = 0; nt < kNT; ++nt) {
+        const int oy = oy0 + wave * kNT + nt;
+        if (oy >= Ho || ox >= Wo) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cg = (g * G::kCoutT + mt * 32) / 8 + q;
+                if (cg >= cg_out) continue;
+                h4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[mt][nt][4 * q + i];
+                    if (do_leaky) v = pwc::leaky(v, slope);
+                    o[i] = (cg * 8 + 4 * kh + i < Cout) ? (_Float16)v : (_Float16)0.f;
+                }
+                *reinterpret_cast<h4 *>(y + (int64_t)b * bsy + ((int64_t)cg * oplane + (int64_t)oy * Wo + ox) * 8 + 4 * kh) = o;
+            }
+        }
+    }
+}
+
+// wp[cgp][tap][kh][CoutP][8] <- w[co][ci = 8*(2*cgp + kh) + j][tap]   (zero outside Cin / Cout)
+__global__ void __launch_bounds__(256)
+pack3x3_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int Cin, int Cout, int CoutP, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i & 7);
+    int64_t t = i >> 3;
+    const int co = (int)(t % CoutP);
+    t /= CoutP;
+    const int kh = (int)(t & 1);
+    t >>= 1;
+    const int tap = (int)(t % 9);
+    const int cgp = (int)(t / 9);
+    const int ci = 8 * (2 * cgp + kh) + j;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * 9 + tap];
+    wp[i] = (_Float16)v;
+}
+
+// [B][C][H][W] f32 -> [B][Cg][H][W][8] f16 (zero channel padding) and back
+__global__ void __launch_bounds__(256)
+nchw_to_c8_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, int Cg, int64_t plane, int64_t total,
+                  int64_t bsx, int64_t bsy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per output pixel-group
+    if (i >= total) return;
+    const int64_t pix = i % plane;
+    int64_t t = i / plane;
+    const int cg = (int)(t % Cg);
+    const int64_t b = t / Cg;
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        o[j] = (c < C) ? (_Float16)x[b * bsx + (int64_t)c * plane + pix] : (_Float16)0.f;
+    }
+    *reinterpret_cast<h8 *>(y + b * bsy + ((int64_t)cg * plane + pix) * 8) = o;
+}
+
+__global__ void __launch_bounds__(256)
+c8_to_nchw_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, int C, int Cg, int64_t plane, int64_t total,
+                  int64_t bsx, int64_t bsy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pix = i % plane;
+    int64_t t = i / plane;
+    const int cg = (int)(t % Cg);
+    const int64_t b = t / Cg;
+    const h8 v = *reinterpret_cast<const h8 *>(x + b * bsx + ((int64_t)cg * plane + pix) * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        if (c < C) y[b * bsy + (int64_t)c * plane + pix] = (float)v[j];
+    }
+}
+
+struct Args16 {
+    const _Float16 *x, *wp;
+    const float *bias;
+    _Float16 *y;
+    int B, Cg, H, W, Cout, CoutP, Ho, Wo;
+    int64_t bsx, bsy;
+    float slope;
+    int do_leaky;
+    hipStream_t stream;
+};
+
+template <int MT, int S, int D>
+int launch16(const Args16 &a) {
+    using G = G16<MT, S, D>;
+    if constexpr (!G::kValid) {
+        PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: internal: MT=%d does not fit for stride %d dilation %d", MT, S, D);
+    } else {
+        const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+        const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
+        const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
+        const int groups = (a.CoutP / 32 + MT - 1) / MT;
+        if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
+        auto kern = conv3x3_f16_kernel<MT, S, D>;
+        static pwc::LdsAttrOnce attr;
+        if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), G::kSmem, a.stream,
+                           a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo, tiles_x, tiles_y,
+                           a.bsx, a.bsy, a.slope, a.do_leaky);
+        return pwc::check_launch("conv3x3_f16_kernel");
+    }
+}
+
+// widest cout tile that fits the LDS for this (stride, dilation); PWC_CONV16F_MT overrides (tuning)
+template <int S, int D>
+int dispatch16(const Args16 &a) {
+    static const int forced = [] { const char *e = getenv("PWC_CONV16F_MT"); return (e && *e) ? atoi(e) : 0; }();
+    const int t32 = a.CoutP / 32;
+    int mt = forced > 0 ? forced : (t32 >= 4 && G16<4, S, D>::kValid ? 4 : (t32 == 3 && G16<3, S, D>::kValid ? 3 : (t32 >= 2 && G16<2, S, D>::kValid ? 2 : 1)));
+    if (mt > t32) mt = t32;
+    switch (mt) {
+        case 4: return launch16<4, S, D>(a);
+        case 3: return launch16<3, S, D>(a);
+        case 2: return launch16<2, S, D>(a);
+        default: return launch16<1, S, D>(a);
+    }
+}
+
+inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
+
+}  // namespace
+
+extern "C" int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return -1;
+    const int cg = (Cin + 7) / 8;
+    return (int64_t)((cg + 1) / 2) * 18 * cout_padded(Cout) * 16;
+}
+
+extern "C" int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream) {
+    if (!w || !wp) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_f16_pack: null pointer");
+    if (Cin <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_f16_pack: bad shape");
+    if (!pwc::aligned16(wp)) PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_f16_pack: packed buffer must be 16-byte aligned");
+    const int64_t total = pwc_conv3x3_f16_packed_bytes(Cin, Cout) / 2;
+    hipLaunchKernelGGL(pack3x3_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(w), static_cast<_Float16 *>(wp), Cin, Cout, cout_padded(Cout), total);
+    return pwc::check_launch("pack3x3_f16_kernel");
+}
+
+extern "C" int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride,
+                                  void *stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_nchw_to_c8_f16: bad argument");
+    if (!pwc::aligned16(y) || (y_bstride % 8)) PWC_FAIL(PWC_EALIGN, "pwc_nchw_to_c8_f16: output must be 16-byte aligned");
+    const int cg = (C + 7) / 8;
+    const int64_t plane = (int64_t)H * W, total = (int64_t)B * cg * plane;
+    hipLaunchKernelGGL(nchw_to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(x), static_cast<_Float16 *>(y), C, cg, plane, total, x_bstride, y_bstride);
+    return pwc::check_launch("nchw_to_c8_kernel");
+}
+
+extern "C" int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride,
+                                  void *stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_c8_f16_to_nchw: bad argument");
+    if (!pwc::aligned16(x) || (x_bstride % 8)) PWC_FAIL(PWC_EALIGN, "pwc_c8_f16_to_nchw: input must be 16-byte aligned");
+    const int cg = (C + 7) / 8;
+    const int64_t plane = (int64_t)H * W, total = (int64_t)B * cg * plane;
+    hipLaunchKernelGGL(c8_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16 *>(x), static_cast<float *>(y), C, cg, plane, total, x_bstride, y_bstride);
+    return pwc::check_launch("c8_to_nchw_kernel");
+}
+
+extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
+                                  int B, int Cin, int H, int W, int Cout, int stride, int dilation,
+                                  unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
+    if (!x || !wp || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: null pointer");
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: bad shape");
+    if (!pwc::aligned16(x) || !pwc::aligned16(y) || !pwc::aligned16(wp) || (x_bstride % 8) || (y_bstride % 8))
+        PWC_FAIL(PWC_EALIGN, "pwc_conv2d_f16_fwd: tensors must be 16-byte aligned with batch strides that are multiples of 8");
+    if (flags & PWC_CONV_RESIDUAL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: residual is not implemented for fp16");
+    const int64_t plane = (int64_t)H * W;
+    const int cg = (Cin + 7) / 8;
+    if (x_bstride < (int64_t)cg * plane * 8) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: x batch stride < Cg*H*W*8");
+    if (plane * 32 >= 0x7fffffffLL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: image plane too large for 32-bit DMA offsets");
+    Args16 a;
+    a.x = static_cast<const _Float16 *>(x);
+    a.wp = static_cast<const _Float16 *>(wp);
+    a.bias = static_cast<const float *>(bias);
+    a.y = static_cast<_Float16 *>(y);
+    a.B = B; a.Cg = cg; a.H = H; a.W = W; a.Cout = Cout; a.CoutP = cout_padded(Cout);
+    a.Ho = (H - 1) / stride + 1;
+    a.Wo = (W - 1) / stride + 1;
+    a.bsx = x_bstride; a.bsy = y_bstride;
+    a.slope = leaky_slope;
+    a.do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
+    a.stream = static_cast<hipStream_t>(stream);
+    if (stride == 1) {
+        switch (dilation) {
+            case 1: return dispatch16<1, 1>(a);
+            case 2: return dispatch16<1, 2>(a);
+            case 4: return dispatch16<1, 4>(a);
+        }
+    } else if (stride == 2 && dilation == 1) {
+        return dispatch16<2, 1>(a);
+    }
+    PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: stride %d dilation %d has no fp16 kernel yet (stride 1: dilation 1,2,4; stride 2: dilation 1)",
+             stride, dilation);
+}
