@@ -119,8 +119,8 @@ int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int s
  * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch
  * stride (in halves, multiple of 8) is free, so a tensor may be a channel-group slice of an arena.  fp32
  * accumulation on v_mfma_f32_32x32x16_f16; bias fp32; optional LeakyReLU; output rounded to half.
- * Same operator as pwc_conv2d_fwd (nn.Conv2d 3x3 + LeakyReLU, PWCNet.py:26-33); stride 1 with dilation 1,2,4 and
- * stride 2 with dilation 1 so far (PWC_EUNSUPPORTED otherwise; no residual). */
+ * Same operator as pwc_conv2d_fwd (nn.Conv2d 3x3 + LeakyReLU, PWCNet.py:26-33): stride 1 with dilation 1,2,4,8,16 and
+ * stride 2 with dilation 1 (PWC_EUNSUPPORTED otherwise; no residual flag). */
 int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout);
 /* w: [Cout,Cin,3,3] f32 (nn.Conv2d layout, device) -> wp: packed halves [Cg/2][tap][2][CoutP][8]. */
 int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream);
@@ -130,6 +130,18 @@ int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
 /* layout conversions at the edges of an fp16 pipeline: NCHW f32 <-> c8 f16 (batch strides in elements) */
 int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
 int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
+
+/* PWC-Net's cost volume (pad 4, kernel 1, max displacement 4, strides 1) on c8 f16 tensors, fp32 accumulation:
+ * in1,in2: [B][ceil(C/8)][H][W][8]; out: [B][11][H][W][8] = 81 displacement channels ((dy+4)*9+(dx+4)) + 7 zeros.
+ * flags: PWC_CORR_NORMALIZE (divide by C instead of multiplying by corr_multiply), PWC_ACT_LEAKY. */
+int pwc_corr81_c8_f16(const void *in1, const void *in2, void *out, int B, int C, int H, int W,
+                      float corr_multiply, unsigned flags, float leaky_slope,
+                      int64_t in1_bstride, int64_t in2_bstride, int64_t out_bstride, void *stream);
+/* PWCDCNet.warp on c8 f16 tensors.  flo: a c8 tensor whose channels flo_channel, flo_channel+1 (same group) hold
+ * (u, v) -- e.g. the arena group that carries up_flow; coordinates and weights in fp32 as in pwc_warp_fwd. */
+int pwc_warp_c8_f16(const void *x, const void *flo, void *out, int B, int C, int H, int W, int flo_channel,
+                    float flow_scale, int align_corners, float mask_threshold,
+                    int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride, void *stream);
 
 /* ConvTranspose2d(kernel 4, stride 2, padding 1) + bias.  x:[B,Cin,H,W], w:[Cin,Cout,4,4] (nn layout),
  * y:[B,Cout,2H,2W]. */

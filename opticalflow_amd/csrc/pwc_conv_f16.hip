@@ -13,7 +13,8 @@
 //   staged input   [kh][row][col][8]         -> B fragment = one ds_read_b128, 32 lanes x 16 B contiguous
 // Workgroup = 4 MFMA waves + 1 loader wave (the fp32 kernels showed that a wave cannot issue LDS-DMA and MFMA
 // back to back; here the bytes per MFMA cycle are 8x higher).  The loader runs a 3-slot ring of 16-channel chunks
-// (input halo tile + filter slab) under a counted vmcnt, one barrier per chunk.  Tile = (8 rows x 32 cols) x 32*MT couts.
+// (input halo tile + filter slab; 2 slots for the wide halos of dilation 8 / 16) under a counted vmcnt, one barrier per
+// chunk.  Tile = (8 rows x 32 cols) x 32*MT couts.
 // Epilogue: bias (fp32), LeakyReLU, round to half, 8-byte stores that interleave to 512 contiguous bytes per wave.
 #include <stdlib.h>
 
@@ -26,16 +27,19 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBlock = 320;          // waves 0..3: MFMA, wave 4: loader
-constexpr int kRing = 3;
 constexpr int kTileW = 32;
 constexpr int kNT = 2;               // rows per wave -> 8-row tiles
 constexpr unsigned kOOB = 0x80000000u;
-static_assert(kRing == 3, "the loader's counted wait assumes exactly one younger chunk in flight");
 
-template <int MT, int S, int D>
+// R = ring depth (3 where the LDS allows it, 2 for the wide halos of dilation 8 / 16).  Dilation 16 stages the three
+// ky row-sets separately (3 x 8 rows instead of 40).
+template <int MT, int S, int D, int R>
 struct G16 {
+    static_assert(R == 2 || R == 3, "ring depth");
+    static constexpr int kRing = R;
     static constexpr int kTileH = 4 * kNT;
-    static constexpr int kInH = (kTileH - 1) * S + 2 * D + 1;
+    static constexpr bool kRowSep = (D >= 16);
+    static constexpr int kInH = kRowSep ? 3 * kTileH : (kTileH - 1) * S + 2 * D + 1;
     static constexpr int kInW = (kTileW - 1) * S + 2 * D + 1;
     static constexpr int kInPieces = 2 * kInH * kInW;             // [kh][row][col] 16-byte pieces per chunk
     static constexpr int kInInstr = (kInPieces + 63) / 64;
@@ -45,8 +49,8 @@ struct G16 {
     static constexpr int kInstr = kInInstr + kWInstr;              // LDS-DMA instructions per chunk (1 KiB each)
     static constexpr int kWOffBytes = kInInstr * 1024;
     static constexpr int kSlotBytes = kInstr * 1024;
-    static constexpr int kSmem = kRing * kSlotBytes;
-    static constexpr bool kValid = kSmem <= 160 * 1024;
+    static constexpr int kSmem = R * kSlotBytes;
+    static constexpr bool kValid = kSmem <= 160 * 1024 && (!kRowSep || S == 1);
 };
 
 // loader wave: start the LDS-DMA of one 16-channel chunk (input halo tile, then the filter slab) into its ring slot
@@ -56,19 +60,19 @@ __device__ __forceinline__ void issue_f16(const _Float16 *xb, const _Float16 *wp
     const int cgv = min(2, Cg - 2 * chunk);               // ragged last pair: kh = 1 is range-checked to zero
     const pwc::v4i32 rin = pwc::make_rsrc(xb + (int64_t)chunk * 2 * plane * 8, cgv * plane * 16);
     const pwc::v4i32 rw = pwc::make_rsrc(wp + (int64_t)chunk * 18 * CoutP * 8, 18 * CoutP * 16);
-    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(smem + (chunk % kRing) * G::kSlotBytes));
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(smem + (chunk % G::kRing) * G::kSlotBytes));
 #pragma unroll
     for (int i = 0; i < G::kInInstr; ++i) pwc::dma_b128(rin, base + i * 1024, off[i]);
 #pragma unroll
     for (int i = 0; i < G::kWInstr; ++i) pwc::dma_b128(rw, base + G::kWOffBytes + i * 1024, off[G::kInInstr + i]);
 }
 
-template <int MT, int S, int D>
+template <int MT, int S, int D, int R>
 __global__ void __launch_bounds__(kBlock)
 conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp, const float *__restrict__ bias,
                    _Float16 *__restrict__ y, int Cg, int H, int W, int Cout, int CoutP, int Ho, int Wo,
                    int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int do_leaky) {
-    using G = G16<MT, S, D>;
+    using G = G16<MT, S, D, R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -95,7 +99,8 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
             const int p = i * 64 + lane;
             const int kh = p / (G::kInH * G::kInW);
             const int rem = p % (G::kInH * G::kInW);
-            const int iy = oy0 * S - D + rem / G::kInW;
+            const int r = rem / G::kInW;
+            const int iy = G::kRowSep ? oy0 + (r % G::kTileH) - D + (r / G::kTileH) * D : oy0 * S - D + r;
             const int ix = ox0 * S - D + rem % G::kInW;
             const bool ok = (p < G::kInPieces) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
             off[i] = ok ? (unsigned)(kh * plane + iy * W + ix) * 16u : kOOB;
@@ -108,12 +113,13 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
             off[G::kInInstr + i] = (q < G::kWPieces && co < CoutP) ? (unsigned)(row * CoutP + co) * 16u : kOOB;
         }
         issue_f16<G>(xb, wp, 0, Cg, plane, CoutP, smem, off);
-        if (nchunks > 1) issue_f16<G>(xb, wp, 1, Cg, plane, CoutP, smem, off);
+        if (R == 3 && nchunks > 1) issue_f16<G>(xb, wp, 1, Cg, plane, CoutP, smem, off);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            if (chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::kInstr) : "memory");
-            else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // consumers may read slot chunk%3; they are done with (chunk-1)%3
-            if (chunk + 2 < nchunks) issue_f16<G>(xb, wp, chunk + 2, Cg, plane, CoutP, smem, off);
+            // chunk has landed; with R == 3 the next one may stay in flight
+            if (R == 3 && chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::kInstr) : "memory");
+            else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // consumers may read slot chunk%R; they are done with (chunk-1)%R
+            if (chunk + R - 1 < nchunks) issue_f16<G>(xb, wp, chunk + R - 1, Cg, plane, CoutP, smem, off);
         }
         return;
     }
@@ -135,8 +141,8 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const unsigned char *cur = smem + (chunk % kRing) * G::kSlotBytes;
-        const h8 *in = reinterpret_cast<const h8 *>(cur) + (kh * G::kInH + wave * kNT * S) * G::kInW + col * S;
+        const unsigned char *cur = smem + (chunk % R) * G::kSlotBytes;
+        const h8 *in = reinterpret_cast<const h8 *>(cur) + (kh * G::kInH + wave * kNT * (G::kRowSep ? 1 : S)) * G::kInW + col * S;
         const h8 *ws = reinterpret_cast<const h8 *>(cur + G::kWOffBytes) + kh * G::kCoutT + col;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -145,7 +151,8 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = ws[tap * 2 * G::kCoutT + mt * 32];
 #pragma unroll
-            for (int nt = 0; nt < kNT; ++nt) bv[nt] = in[(nt * S + ky * D) * G::kInW + kx * D];
+            for (int nt = 0; nt < kNT; ++nt)
+                bv[nt] = in[(G::kRowSep ? nt + ky * G::kTileH : nt * S + ky * D) * G::kInW + kx * D];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -248,9 +255,9 @@ struct Args16 {
     hipStream_t stream;
 };
 
-template <int MT, int S, int D>
+template <int MT, int S, int D, int R>
 int launch16(const Args16 &a) {
-    using G = G16<MT, S, D>;
+    using G = G16<MT, S, D, R>;
     if constexpr (!G::kValid) {
         PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: internal: MT=%d does not fit for stride %d dilation %d", MT, S, D);
     } else {
@@ -259,7 +266,7 @@ int launch16(const Args16 &a) {
         const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
         const int groups = (a.CoutP / 32 + MT - 1) / MT;
         if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
-        auto kern = conv3x3_f16_kernel<MT, S, D>;
+        auto kern = conv3x3_f16_kernel<MT, S, D, R>;
         static pwc::LdsAttrOnce attr;
         if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), G::kSmem, a.stream,
@@ -269,19 +276,24 @@ int launch16(const Args16 &a) {
     }
 }
 
-// widest cout tile that fits the LDS for this (stride, dilation); PWC_CONV16F_MT overrides (tuning)
+// widest cout tile that fits the LDS for this (stride, dilation), with a 3-slot ring if possible, else 2 slots;
+// PWC_CONV16F_MT / PWC_CONV16F_RING override (tuning)
 template <int S, int D>
 int dispatch16(const Args16 &a) {
-    static const int forced = [] { const char *e = getenv("PWC_CONV16F_MT"); return (e && *e) ? atoi(e) : 0; }();
+    static const int forced_mt = [] { const char *e = getenv("PWC_CONV16F_MT"); return (e && *e) ? atoi(e) : 0; }();
+    static const int forced_r = [] { const char *e = getenv("PWC_CONV16F_RING"); return (e && *e) ? atoi(e) : 0; }();
     const int t32 = a.CoutP / 32;
-    int mt = forced > 0 ? forced : (t32 >= 4 && G16<4, S, D>::kValid ? 4 : (t32 == 3 && G16<3, S, D>::kValid ? 3 : (t32 >= 2 && G16<2, S, D>::kValid ? 2 : 1)));
-    if (mt > t32) mt = t32;
-    switch (mt) {
-        case 4: return launch16<4, S, D>(a);
-        case 3: return launch16<3, S, D>(a);
-        case 2: return launch16<2, S, D>(a);
-        default: return launch16<1, S, D>(a);
+    const int want = forced_mt > 0 ? min(forced_mt, t32) : min(t32, 4);
+#define PWC_TRY(MT_, R_)                                                                                   \
+    if (mt == MT_ && (forced_r == 0 || forced_r == R_)) {                                                  \
+        if constexpr (G16<MT_, S, D, R_>::kValid) return launch16<MT_, S, D, R_>(a);                       \
     }
+    for (int mt = want; mt >= 1; --mt) {
+        PWC_TRY(4, 3) PWC_TRY(3, 3) PWC_TRY(2, 3) PWC_TRY(1, 3)
+        PWC_TRY(4, 2) PWC_TRY(3, 2) PWC_TRY(2, 2) PWC_TRY(1, 2)
+    }
+#undef PWC_TRY
+    PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: no tile fits the LDS for stride %d dilation %d", S, D);
 }
 
 inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
@@ -355,10 +367,12 @@ extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bia
             case 1: return dispatch16<1, 1>(a);
             case 2: return dispatch16<1, 2>(a);
             case 4: return dispatch16<1, 4>(a);
+            case 8: return dispatch16<1, 8>(a);
+            case 16: return dispatch16<1, 16>(a);
         }
     } else if (stride == 2 && dilation == 1) {
         return dispatch16<2, 1>(a);
     }
-    PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: stride %d dilation %d has no fp16 kernel yet (stride 1: dilation 1,2,4; stride 2: dilation 1)",
+    PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: stride %d dilation %d has no fp16 kernel (stride 1: dilation 1,2,4,8,16; stride 2: dilation 1)",
              stride, dilation);
 }

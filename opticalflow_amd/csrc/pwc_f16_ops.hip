@@ -1,0 +1,210 @@
+// Half-precision correlation and warp on channel-blocked ("c8") activations [B][ceil(C/8)][H][W][8] -- the
+// HBM-bound companions of the fp16 MFMA convolution (pwc_conv_f16.hip).  fp32 accumulation / coordinates.
+//
+//   corr81_c8_kernel : PWC-Net's cost volume (pad 4, kernel 1, max displacement 4, strides 1; reference
+//                      models/correlation_package/correlation.py:12-40, correlation_cuda_kernel.cu:73-147) + fused
+//                      scale and LeakyReLU, written as 11 channel groups (81 channels + 7 zeros) so that it can land
+//                      directly in an arena slot.  One thread = one pixel x 81 displacements: channel-innermost data
+//                      makes the inner product a chain of v_dot2_f32_f16 on 16-byte LDS reads; the in2 halo tile of a
+//                      chunk of 4 channel groups is staged by LDS-DMA (zero padding = range check).
+//   warp_c8_kernel   : PWCDCNet.warp (models/PWCNet.py:141-177), same coordinate arithmetic and mask rule as the fp32
+//                      kernel (pwc_warp.hip); a tap is one 16-byte gather per channel group.
+#include "pwc_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kOOB = 0x80000000u;
+
+// ---- correlation -------------------------------------------------------------------------------------------
+constexpr int kCTH = 8, kCTW = 32;                   // pixel tile
+constexpr int kCHaloH = kCTH + 8, kCHaloW = kCTW + 8;
+constexpr int kCGroups = 4;                           // channel groups (32 channels) staged per step
+constexpr int kCPieces = kCGroups * kCHaloH * kCHaloW;           // 2560 16-byte pieces
+constexpr int kCThreads = 256;
+constexpr int kCInstr = kCPieces / kCThreads;          // 10 LDS-DMA instructions per wave and step
+static_assert(kCPieces % kCThreads == 0, "tile pieces must divide evenly");
+
+__device__ __forceinline__ float dot8(h8 a, h8 b, float acc) {
+    acc = __builtin_amdgcn_fdot2(h2{a[0], a[1]}, h2{b[0], b[1]}, acc, false);
+    acc = __builtin_amdgcn_fdot2(h2{a[2], a[3]}, h2{b[2], b[3]}, acc, false);
+    acc = __builtin_amdgcn_fdot2(h2{a[4], a[5]}, h2{b[4], b[5]}, acc, false);
+    acc = __builtin_amdgcn_fdot2(h2{a[6], a[7]}, h2{b[6], b[7]}, acc, false);
+    return acc;
+}
+
+__global__ void __launch_bounds__(kCThreads)
+corr81_c8_kernel(const _Float16 *__restrict__ in1, const _Float16 *__restrict__ in2, _Float16 *__restrict__ out,
+                 int Cg, int H, int W, int tiles_x, int tiles_y, int64_t bs1, int64_t bs2, int64_t bso,
+                 float scale, float slope, int do_leaky) {
+    __shared__ __attribute__((aligned(16))) h8 tile[kCPieces];           // [g][row 16][col 40]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * kCTW, y0 = ty * kCTH;
+    const int plane = H * W;
+    const int px = tid & 31, py = tid >> 5;
+    const int x = x0 + px, y = y0 + py;
+    const bool inside = (x < W) && (y < H);
+
+    // per-lane source offsets of this wave's DMA instructions (pieces wave*64 + lane + 256*i)
+    unsigned off[kCInstr];
+#pragma unroll
+    for (int i = 0; i < kCInstr; ++i) {
+        const int p = i * kCThreads + wave * 64 + lane;
+        const int g = p / (kCHaloH * kCHaloW);
+        const int rem = p % (kCHaloH * kCHaloW);
+        const int iy = y0 - 4 + rem / kCHaloW;
+        const int ix = x0 - 4 + rem % kCHaloW;
+        const bool ok = (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+        off[i] = ok ? (unsigned)(g * plane + iy * W + ix) * 16u : kOOB;
+    }
+
+    float acc[81];
+#pragma unroll
+    for (int d = 0; d < 81; ++d) acc[d] = 0.f;
+
+    const _Float16 *p1 = in1 + (int64_t)b * bs1;
+    const _Float16 *p2 = in2 + (int64_t)b * bs2;
+    for (int g0 = 0; g0 < Cg; g0 += kCGroups) {
+        const int gv = min(kCGroups, Cg - g0);
+        const pwc::v4i32 r2 = pwc::make_rsrc(p2 + (int64_t)g0 * plane * 8, gv * plane * 16);
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(tile)) + wave * 1024;
+        __syncthreads();                                   // previous step's reads are done
+#pragma unroll
+        for (int i = 0; i < kCInstr; ++i) pwc::dma_b128(r2, base + i * (kCThreads * 16), off[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int g = 0; g < gv; ++g) {
+            h8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (inside) a = *reinterpret_cast<const h8 *>(p1 + ((int64_t)(g0 + g) * plane + (int64_t)y * W + x) * 8);
+            const h8 *t = tile + (g * kCHaloH + py) * kCHaloW + px;
+#pragma unroll
+            for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 9; ++dx)
+                    acc[dy * 9 + dx] = dot8(a, t[dy * kCHaloW + dx], acc[dy * 9 + dx]);
+        }
+    }
+    if (!inside) return;
+    _Float16 *po = out + (int64_t)b * bso + ((int64_t)y * W + x) * 8;
+#pragma unroll
+    for (int g = 0; g < 11; ++g) {
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = g * 8 + j;
+            float v = 0.f;
+            if (d < 81) {
+                v = acc[d < 81 ? d : 0] * scale;
+                if (do_leaky) v = pwc::leaky(v, slope);
+            }
+            o[j] = (_Float16)v;
+        }
+        *reinterpret_cast<h8 *>(po + (int64_t)g * plane * 8) = o;
+    }
+}
+
+// ---- warp ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo, _Float16 *__restrict__ out,
+               int Cg, int H, int W, int64_t npix, int flo_channel, int64_t bsx, int64_t bsf, int64_t bso,
+               float flow_scale, int align_corners, float thr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int64_t plane = (int64_t)H * W;
+    const int b = (int)(i / plane);
+    const int pix = (int)(i - (int64_t)b * plane);
+    const int yy = pix / W, xx = pix - yy * W;
+    const _Float16 *f = flo + (int64_t)b * bsf + (int64_t)pix * 8 + flo_channel;
+    const float u = (float)f[0] * flow_scale, v = (float)f[1] * flow_scale;
+    // same arithmetic as pwc_warp.hip::make_taps (PWCNet.py:162-163 + grid_sample's un-normalisation)
+    const float gx = 2.0f * ((float)xx + u) / (float)max(W - 1, 1) - 1.0f;
+    const float gy = 2.0f * ((float)yy + v) / (float)max(H - 1, 1) - 1.0f;
+    float ix, iy;
+    if (align_corners) {
+        ix = (gx + 1.0f) / 2.0f * (float)(W - 1);
+        iy = (gy + 1.0f) / 2.0f * (float)(H - 1);
+    } else {
+        ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+        iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    }
+    ix = fminf(fmaxf(ix, -16.0f), (float)W + 16.0f);
+    iy = fminf(fmaxf(iy, -16.0f), (float)H + 16.0f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float ax1 = ix - fx, ay1 = iy - fy, ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
+    const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x0 + 1 >= 0) && (x0 + 1 < W);
+    const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y0 + 1 >= 0) && (y0 + 1 < H);
+    float w00 = (vx0 && vy0) ? ay0 * ax0 : 0.f, w01 = (vx1 && vy0) ? ay0 * ax1 : 0.f;
+    float w10 = (vx0 && vy1) ? ay1 * ax0 : 0.f, w11 = (vx1 && vy1) ? ay1 * ax1 : 0.f;
+    const float msum = ((w00 + w01) + w10) + w11;
+    if (!(msum >= thr)) w00 = w01 = w10 = w11 = 0.f;
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    const int64_t o00 = ((int64_t)yc0 * W + xc0) * 8, o01 = ((int64_t)yc0 * W + xc1) * 8;
+    const int64_t o10 = ((int64_t)yc1 * W + xc0) * 8, o11 = ((int64_t)yc1 * W + xc1) * 8;
+    const _Float16 *src = x + (int64_t)b * bsx;
+    _Float16 *dst = out + (int64_t)b * bso + (int64_t)pix * 8;
+    for (int g = 0; g < Cg; ++g, src += plane * 8, dst += plane * 8) {
+        const h8 a = *reinterpret_cast<const h8 *>(src + o00), bq = *reinterpret_cast<const h8 *>(src + o01);
+        const h8 c = *reinterpret_cast<const h8 *>(src + o10), d = *reinterpret_cast<const h8 *>(src + o11);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = (_Float16)((((float)a[j] * w00 + (float)bq[j] * w01) + (float)c[j] * w10) + (float)d[j] * w11);
+        *reinterpret_cast<h8 *>(dst) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int pwc_corr81_c8_f16(const void *in1, const void *in2, void *out, int B, int C, int H, int W,
+                                 float corr_multiply, unsigned flags, float leaky_slope,
+                                 int64_t in1_bstride, int64_t in2_bstride, int64_t out_bstride, void *stream) {
+    if (!in1 || !in2 || !out) PWC_FAIL(PWC_EINVAL, "pwc_corr81_c8_f16: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_corr81_c8_f16: bad shape");
+    if (!pwc::aligned16(in1) || !pwc::aligned16(in2) || !pwc::aligned16(out) || (in1_bstride % 8) || (in2_bstride % 8) || (out_bstride % 8))
+        PWC_FAIL(PWC_EALIGN, "pwc_corr81_c8_f16: tensors must be 16-byte aligned with batch strides that are multiples of 8");
+    const int64_t plane = (int64_t)H * W;
+    const int cg = (C + 7) / 8;
+    if (in1_bstride < cg * plane * 8 || in2_bstride < cg * plane * 8 || out_bstride < 11 * plane * 8)
+        PWC_FAIL(PWC_EINVAL, "pwc_corr81_c8_f16: batch stride smaller than the tensor");
+    if (plane * 16 * kCGroups >= 0x7fffffffLL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr81_c8_f16: image plane too large for 32-bit DMA offsets");
+    const int tiles_x = (W + kCTW - 1) / kCTW, tiles_y = (H + kCTH - 1) / kCTH;
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr81_c8_f16: grid too large");
+    const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
+    hipLaunchKernelGGL(corr81_c8_kernel, dim3((unsigned)nblk), dim3(kCThreads), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16 *>(in1), static_cast<const _Float16 *>(in2), static_cast<_Float16 *>(out),
+                       cg, H, W, tiles_x, tiles_y, in1_bstride, in2_bstride, out_bstride, scale, leaky_slope,
+                       (flags & PWC_ACT_LEAKY) ? 1 : 0);
+    return pwc::check_launch("corr81_c8_kernel");
+}
+
+extern "C" int pwc_warp_c8_f16(const void *x, const void *flo, void *out, int B, int C, int H, int W, int flo_channel,
+                               float flow_scale, int align_corners, float mask_threshold,
+                               int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride, void *stream) {
+    if (!x || !flo || !out) PWC_FAIL(PWC_EINVAL, "pwc_warp_c8_f16: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_warp_c8_f16: bad shape");
+    if (flo_channel < 0 || flo_channel > 6) PWC_FAIL(PWC_EINVAL, "pwc_warp_c8_f16: (u,v) must be channels k,k+1 of ONE group (k=%d)", flo_channel);
+    if (!pwc::aligned16(x) || !pwc::aligned16(out) || (x_bstride % 8) || (out_bstride % 8))
+        PWC_FAIL(PWC_EALIGN, "pwc_warp_c8_f16: tensors must be 16-byte aligned with batch strides that are multiples of 8");
+    if (x == out) PWC_FAIL(PWC_EINVAL, "pwc_warp_c8_f16: in-place warp is not defined");
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t nblk = (npix + 255) / 256;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_warp_c8_f16: grid too large");
+    hipLaunchKernelGGL(warp_c8_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16 *>(x), static_cast<const _Float16 *>(flo), static_cast<_Float16 *>(out),
+                       (C + 7) / 8, H, W, npix, flo_channel, x_bstride, flo_bstride, out_bstride,
+                       flow_scale, align_corners, mask_threshold);
+    return pwc::check_launch("warp_c8_kernel");
+}

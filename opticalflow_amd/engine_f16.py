@@ -1,0 +1,214 @@
+"""Half-precision execution plan of PWCDCNet.forward (BASELINE configs 3-4): same launch order as engine.PwcPlan, with
+
+  * activations in the channel-blocked "c8" layout ``[B, ceil(C/8), H, W, 8]`` float16 (ops_f16), fp32 accumulation in
+    every kernel, fp32 biases;
+  * one arena per level in GROUPS of 8 channels
+        [conv_4 (4) | conv_3 (8) | conv_2 (12) | conv_1 (16) | conv_0 (16) | corr (11 = 81 ch + 7 zeros) | c1 (C_L/8) | flow (1)]
+    where the flow group carries up_flow in channels 0,1 and up_feat in channels 2,3 (4..7 zero).  Filters are
+    re-indexed from the reference's concatenation order (models/PWCNet.py:215,229,245,259 and the new-features-first
+    dense concat :202-206) to this physical order, with zero filters on the pad channels;
+  * the 2-channel layers as MFMA convolutions: ``predict_flowL`` and ``upfeatL`` read the same 3x3 windows, and a
+    ConvTranspose2d(k4, s2, p1) is a 3x3 convolution with 4 output phases per channel followed by a pixel shuffle
+    (PWCNet.py:35-36), so head + upfeat are ONE convolution with 16 output channels (flow in group 0, the 8 upfeat
+    phases in group 1) and ``deconvL`` is a second one on the flow group; the shuffles are strided copies.
+
+Inference (eval) only, PWCDCNet variant "dc".  Input/outputs stay float32 NCHW like the reference's interface.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import ops_f16 as F16
+from .engine import CONTEXT, DENSE_OUT, LEAKY, PYRAMID_CH, PYRAMID_NAMES, WARP_SCALE, level_in_channels
+
+DENSE_G = (40, 24, 12, 4, 0)          # group offset of conv{L}_i's output (conv_0 .. conv_4) inside the arena
+BASE_G = 56                           # first group after the dense-block outputs
+CORR_G = 11                           # 81 channels + 7 zeros
+
+
+def _groups(c: int) -> int:
+    return (c + 7) // 8
+
+
+def _pad_cin(w: torch.Tensor, phys: int) -> torch.Tensor:
+    out = w.new_zeros((w.shape[0], phys, 3, 3))
+    out[:, :w.shape[1]] = w
+    return out
+
+
+def _deconv_as_conv3x3(wt: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(k4, s2, p1) filters [Cin, Cout, 4, 4] -> 3x3 conv filters [Cout*4, Cin, 3, 3], output channel
+    co*4 + py*2 + px = phase (py, px) of output pixel (2*iy+py, 2*ix+px):
+    py = 0 takes window rows a = 0, 1 with ky = 3, 1;  py = 1 takes a = 1, 2 with ky = 2, 0  (same along x)."""
+    cin, cout = wt.shape[:2]
+    k = wt.new_zeros((cout, 2, 2, cin, 3, 3))
+    taps = {0: ((0, 3), (1, 1)), 1: ((1, 2), (2, 0))}          # phase -> ((window index, kernel index), ...)
+    for py in (0, 1):
+        for a, ky in taps[py]:
+            for px in (0, 1):
+                for e, kx in taps[px]:
+                    k[:, py, px, :, a, e] = wt[:, :, ky, kx].t()
+    return k.reshape(cout * 4, cin, 3, 3)
+
+
+def _phys_index(level: int, nd: int = 81) -> torch.Tensor:
+    """reference channel r of the level's full concatenation -> physical channel of the c8 arena."""
+    c = PYRAMID_CH[level]
+    idx = list(range(448)) + [448 + i for i in range(nd)]
+    if level < 6:
+        feat0 = 448 + CORR_G * 8
+        idx += [feat0 + i for i in range(c)]
+        idx += [feat0 + c + i for i in range(4)]               # up_flow 0,1 then up_feat 0,1 = channels 0..3 of the flow group
+    return torch.tensor(idx, dtype=torch.long)
+
+
+class PwcPlanF16:
+    def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device, md: int = 4,
+                 normalize_corr: bool = False, align_corners: bool = False):
+        if H % 64 or W % 64 or H <= 0 or W <= 0:
+            raise ValueError("PWCDCNet needs H and W to be positive multiples of 64 (got %dx%d)" % (H, W))
+        if md != 4:
+            raise NotImplementedError("the fp16 correlation kernel is built for md=4")
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.normalize_corr, self.align_corners = normalize_corr, align_corners
+        self.nd = 81
+        hk = dict(device=device, dtype=torch.float16)
+        self.size = {l: (H >> l, W >> l) for l in range(1, 7)}
+        self.img = torch.zeros((2 * B, 1, H, W, 8), **hk)
+        self.pyr_a, self.pyr_b = {}, {}
+        for l in range(1, 7):
+            h, w = self.size[l]
+            g = _groups(PYRAMID_CH[l])
+            self.pyr_a[l] = torch.zeros((2 * B, g, h, w, 8), **hk)
+            self.pyr_b[l] = torch.zeros((2 * B, g, h, w, 8), **hk)
+        self.arena, self.warped, self.head, self.upflow = {}, {}, {}, {}
+        for l in range(2, 7):
+            h, w = self.size[l]
+            g = _groups(PYRAMID_CH[l])
+            self.arena[l] = torch.zeros((B, BASE_G + CORR_G + (g + 1 if l < 6 else 0), h, w, 8), **hk)
+            if l < 6:
+                self.warped[l] = torch.zeros((B, g, h, w, 8), **hk)
+            self.head[l] = torch.zeros((B, 2 if l > 2 else 1, h, w, 8), **hk)
+            if l > 2:
+                self.upflow[l] = torch.zeros((B, 1, h, w, 8), **hk)
+        h2, w2 = self.size[2]
+        self.ctx = [torch.zeros((B, _groups(c), h2, w2, 8), **hk) for c, _ in CONTEXT]
+        self.dc7 = torch.zeros((B, 1, h2, w2, 8), **hk)
+        self.flow_out = torch.empty((B, 2, h2, w2), device=device, dtype=torch.float32)
+
+        # ---- filters: re-index to the physical channel order, pad, pack --------------------------------------------
+        self.w: Dict[str, torch.Tensor] = {}
+        self.b: Dict[str, torch.Tensor] = {}
+        self.cin: Dict[str, int] = {}
+        self.cout: Dict[str, int] = {}
+
+        def put(name, w, bias):
+            self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float())
+            self.b[name] = bias.contiguous().float()
+            self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
+
+        p = {k: v.detach().float() for k, v in params.items()}
+        for l, names in enumerate(PYRAMID_NAMES, start=1):
+            for i, n in enumerate(names):
+                w = p[n + ".0.weight"]
+                phys = 8 if (l == 1 and i == 0) else _groups(w.shape[1]) * 8
+                put(n, _pad_cin(w, phys), p[n + ".0.bias"])
+        for l in range(2, 7):
+            full = _phys_index(l)
+            nphys = int(self.arena[l].shape[1]) * 8
+            od = level_in_channels(l, self.nd)
+
+            def remap(w, ref_start, phys_start):
+                out = w.new_zeros((w.shape[0], nphys - phys_start, 3, 3))
+                ref = torch.arange(ref_start, ref_start + w.shape[1])
+                out[:, full[ref] - phys_start] = w
+                return out
+
+            ref_start = 448                                      # conv_0 reads corr.. ; each next conv one more dense output
+            for i, co in enumerate(DENSE_OUT):
+                put("conv%d_%d" % (l, i), remap(p["conv%d_%d.0.weight" % (l, i)], ref_start, ref_start), p["conv%d_%d.0.bias" % (l, i)])
+                ref_start -= co
+            assert ref_start == 0 and od + 448 == full.numel()
+            wh, bh = p["predict_flow%d.weight" % l], p["predict_flow%d.bias" % l]
+            if l > 2:
+                wu = _deconv_as_conv3x3(p["upfeat%d.weight" % l])            # [8, Cin_ref, 3, 3]
+                k = wh.new_zeros((16, wh.shape[1], 3, 3))
+                k[0:2], k[8:16] = wh, wu
+                bias = bh.new_zeros(16)
+                bias[0:2] = bh
+                bias[8:16] = p["upfeat%d.bias" % l].repeat_interleave(4)
+                put("head%d" % l, remap(k, 0, 0), bias)
+                wd = _deconv_as_conv3x3(p["deconv%d.weight" % l])            # [8, 2, 3, 3]
+                put("deconv%d" % l, _pad_cin(wd, 8), p["deconv%d.bias" % l].repeat_interleave(4))
+            else:
+                put("head2", remap(wh, 0, 0), bh)
+                put("dc_conv1", remap(p["dc_conv1.0.weight"], 0, 0), p["dc_conv1.0.bias"])
+        for i in range(2, 7):
+            w = p["dc_conv%d.0.weight" % i]
+            put("dc_conv%d" % i, _pad_cin(w, _groups(w.shape[1]) * 8), p["dc_conv%d.0.bias" % i])
+        put("dc_conv7", _pad_cin(p["dc_conv7.weight"], 32), p["dc_conv7.bias"])
+
+    # ---- primitives -------------------------------------------------------------------------------------------------
+    def _conv(self, name, x, out, stride=1, dilation=1, act=True):
+        F16.conv3x3_f16(x, self.w[name], self.b[name], self.cin[name], self.cout[name], stride=stride, dilation=dilation,
+                        leaky_slope=LEAKY if act else None, out=out)
+
+    @staticmethod
+    def _shuffle(phases: torch.Tensor, dst: torch.Tensor) -> None:
+        """phases [B,h,w,8] (channel = co*4 + py*2 + px) -> dst [B,2h,2w,2] (strided view into a flow group)."""
+        B, h, w, _ = phases.shape
+        dst.copy_(phases.view(B, h, w, 2, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * h, 2 * w, 2))
+
+    # ---- the forward ----------------------------------------------------------------------------------------------------
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        B = self.B
+        if tuple(x.shape) != (B, 6, self.H, self.W) or x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError("plan built for float32 %s on %s, got %s %s on %s" % (
+                (B, 6, self.H, self.W), self.device, x.dtype, tuple(x.shape), x.device))
+        F16.to_c8(x[:, :3], out=self.img[:B])
+        F16.to_c8(x[:, 3:], out=self.img[B:])
+        prev = self.img
+        for l in range(1, 7):
+            na, naa, nb = PYRAMID_NAMES[l - 1]
+            a, bb = self.pyr_a[l], self.pyr_b[l]
+            self._conv(na, prev, a, stride=2)
+            self._conv(naa, a, bb)
+            self._conv(nb, bb, a)
+            prev = a
+        for l in (6, 5, 4, 3, 2):
+            ar = self.arena[l]
+            g = _groups(PYRAMID_CH[l])
+            c1, c2 = self.pyr_a[l][:B], self.pyr_a[l][B:]
+            corr_slot = ar[:, BASE_G:BASE_G + CORR_G]
+            if l == 6:
+                F16.correlation_c8(c1, c2, PYRAMID_CH[6], normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+            else:
+                f0 = BASE_G + CORR_G
+                ar[:, f0:f0 + g].copy_(c1)
+                F16.warp_c8(c2, ar[:, f0 + g:f0 + g + 1], PYRAMID_CH[l], flo_channel=0, flow_scale=WARP_SCALE[l],
+                            align_corners=self.align_corners, out=self.warped[l])
+                F16.correlation_c8(c1, self.warped[l], PYRAMID_CH[l], normalize=self.normalize_corr, leaky_slope=LEAKY,
+                                   out=corr_slot)
+            lo = BASE_G
+            for i, og in enumerate(DENSE_G):
+                self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, og:og + DENSE_OUT[i] // 8])
+                lo = og
+            self._conv("head%d" % l, ar, self.head[l], act=False)
+            if l > 2:
+                self._conv("deconv%d" % l, self.head[l][:, 0:1], self.upflow[l], act=False)
+                nxt = self.arena[l - 1]
+                fg = nxt[:, nxt.shape[1] - 1]                     # the flow group of the next level [B,2h,2w,8]
+                self._shuffle(self.upflow[l][:, 0], fg[..., 0:2])
+                self._shuffle(self.head[l][:, 1], fg[..., 2:4])
+        t = self.arena[2]
+        for i, (_, dil) in enumerate(CONTEXT):
+            self._conv("dc_conv%d" % (i + 1), t, self.ctx[i], dilation=dil)
+            t = self.ctx[i]
+        self._conv("dc_conv7", t, self.dc7, act=False)
+        # flow2 = predict_flow2 + dc_conv7 (PWCNet.py:268), summed in fp32, channels 0,1 of the one-group tensors
+        h2, w2 = self.size[2]
+        s = self.head[2][:, 0, :, :, 0:2].float() + self.dc7[:, 0, :, :, 0:2].float()
+        self.flow_out.copy_(s.permute(0, 3, 1, 2))
+        return self.flow_out

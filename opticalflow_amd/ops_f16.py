@@ -109,3 +109,44 @@ def conv3x3_f16(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cin:
                                     float(leaky_slope or 0.0), bsx, bsy, _stream(x))
     check(rc, "pwc_conv2d_f16_fwd")
     return out
+
+
+def correlation_c8(in1: torch.Tensor, in2: torch.Tensor, channels: int, corr_multiply: float = 1.0, normalize: bool = False,
+                   leaky_slope: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PWC-Net cost volume (pad 4, k 1, d 4, strides 1) on c8 tensors -> [B,11,H,W,8] (81 channels + 7 zeros)."""
+    lib = _lib.load()
+    bs1, bs2 = _c8_bstride(in1, "in1"), _c8_bstride(in2, "in2")
+    if in1.shape != in2.shape or in1.shape[1] != (channels + 7) // 8:
+        raise ValueError("in1/in2 must both be %d channel groups, got %s / %s" % ((channels + 7) // 8, tuple(in1.shape), tuple(in2.shape)))
+    B, _, H, W, _ = in1.shape
+    if out is None:
+        out = torch.empty((B, 11, H, W, 8), dtype=torch.float16, device=in1.device)
+    elif tuple(out.shape) != (B, 11, H, W, 8):
+        raise ValueError("out must be %s" % ((B, 11, H, W, 8),))
+    bso = _c8_bstride(out, "out")
+    flags = (_lib.FLAG_CORR_NORMALIZE if normalize else 0) | (FLAG_ACT_LEAKY if leaky_slope is not None else 0)
+    with torch.cuda.device(in1.device):
+        rc = lib.pwc_corr81_c8_f16(in1.data_ptr(), in2.data_ptr(), out.data_ptr(), B, channels, H, W, float(corr_multiply),
+                                   flags, float(leaky_slope or 0.0), bs1, bs2, bso, _stream(in1))
+    check(rc, "pwc_corr81_c8_f16")
+    return out
+
+
+def warp_c8(x: torch.Tensor, flo: torch.Tensor, channels: int, flo_channel: int = 0, flow_scale: float = 1.0,
+            align_corners: bool = False, mask_threshold: float = 0.9999, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PWCDCNet.warp on c8 tensors; `flo` is a ONE-group c8 tensor [B,1,H,W,8] with (u,v) at channels flo_channel, +1."""
+    lib = _lib.load()
+    bsx, bsf = _c8_bstride(x, "x"), _c8_bstride(flo, "flo")
+    B, cg, H, W, _ = x.shape
+    if cg != (channels + 7) // 8 or tuple(flo.shape) != (B, 1, H, W, 8):
+        raise ValueError("x must have %d groups and flo must be %s" % ((channels + 7) // 8, (B, 1, H, W, 8)))
+    if out is None:
+        out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    elif out.shape != x.shape:
+        raise ValueError("out must match x")
+    bso = _c8_bstride(out, "out")
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_warp_c8_f16(x.data_ptr(), flo.data_ptr(), out.data_ptr(), B, channels, H, W, int(flo_channel),
+                                 float(flow_scale), 1 if align_corners else 0, float(mask_threshold), bsx, bsf, bso, _stream(x))
+    check(rc, "pwc_warp_c8_f16")
+    return out

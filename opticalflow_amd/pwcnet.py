@@ -48,8 +48,13 @@ class PWCDCNet(nn.Module):
     _pyramid_names = PYRAMID_NAMES
 
     def __init__(self, md: int = 4, normalize_corr: bool = False, align_corners: bool = False,
-                 conv_backend: str = "hip", use_graph: bool = False):
+                 conv_backend: str = "hip", use_graph: bool = False, precision: str = "fp32"):
         super().__init__()
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' or 'fp16'")
+        # 'fp16' (BASELINE configs 3-4): float32 parameters and float32 input/output as in the reference's interface,
+        # half-precision activations and filters inside, fp32 accumulation (engine_f16.PwcPlanF16); eval mode only
+        self.precision = precision
         self.md = md
         self.normalize_corr = normalize_corr
         self.align_corners = align_corners
@@ -110,6 +115,9 @@ class PWCDCNet(nn.Module):
         if not x.is_cuda:
             raise PwcHipError("PWCDCNet.forward needs a tensor on the ROCm device (got %s): the HIP path has no "
                               "CPU fallback" % x.device)
+        if self.training and self.precision == "fp16":
+            raise NotImplementedError("precision='fp16' is inference only (call .eval()): the 5-tuple of training mode "
+                                      "is produced by the fp32 plan")
         plan = self._plan_for(x)
         key = self._key(x)
         if self.use_graph and not self.training:
@@ -123,7 +131,7 @@ class PWCDCNet(nn.Module):
     # ---- plan management -----------------------------------------------------------------------
     def _key(self, x):
         return (x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device, self.conv_backend,
-                self.normalize_corr, self.align_corners)
+                self.normalize_corr, self.align_corners, self.precision)
 
     def _param_versions(self):
         # in-place updates bump _version; re-homing (.to/.cuda/load_state_dict) goes through _apply /
@@ -153,8 +161,15 @@ class PWCDCNet(nn.Module):
                                       % (k, v.device, x.device))
                 if v.dtype != torch.float32:
                     raise NotImplementedError("parameters must be float32 (got %s for %s)" % (v.dtype, k))
-            plan = PwcPlan(params, x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype, self.md,
-                           self.normalize_corr, self.align_corners, self.conv_backend, self.variant)
+            if self.precision == "fp16":
+                if self.variant != "dc" or self.conv_backend != "hip" or x.dtype != torch.float32:
+                    raise NotImplementedError("precision='fp16' is built for PWCDCNet, conv_backend='hip', float32 input")
+                from .engine_f16 import PwcPlanF16
+                plan = PwcPlanF16(params, x.shape[0], x.shape[2], x.shape[3], x.device, self.md,
+                                  self.normalize_corr, self.align_corners)
+            else:
+                plan = PwcPlan(params, x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype, self.md,
+                               self.normalize_corr, self.align_corners, self.conv_backend, self.variant)
             self._plans[key] = plan
         return plan
 

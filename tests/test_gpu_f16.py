@@ -44,6 +44,8 @@ F16_CASES = [
     (1, 533, 32, 12, 64, 1, 1, True),
     (1, 128, 128, 24, 40, 1, 2, True),
     (1, 128, 128, 24, 40, 1, 4, True),
+    (1, 128, 96, 24, 40, 1, 8, True),           # 2-slot ring (wide halo)
+    (2, 96, 64, 40, 72, 1, 16, True),           # three ky row-sets staged separately
     (2, 3, 16, 33, 70, 2, 1, True),             # image layer: 3 channels padded to one group
     (1, 96, 196, 14, 32, 2, 1, True),           # Cout not a multiple of 8
     (1, 64, 2, 9, 33, 1, 1, False),             # flow head, no activation
@@ -92,6 +94,83 @@ def test_conv3x3_f16_arena_slices_and_errors(dev):
     assert (arena[:, :7] == 7).all()
     assert torch.equal(F16.from_c8(arena[:, 15:], cin).cpu(), x)                     # batch-strided operand
     with pytest.raises(PwcHipError):
-        F16.conv3x3_f16(arena[:, 15:], wp, bias.to(dev), cin, cout, dilation=8)       # no fp16 kernel for dilation 8 yet
+        F16.conv3x3_f16(arena[:, 15:], wp, bias.to(dev), cin, cout, dilation=3)       # PWC-Net has no dilation 3
     with pytest.raises(ValueError):
         F16.conv3x3_f16(arena[:, 15:], wp, bias.to(dev), cin + 8, cout)
+
+
+def _to_c8_cpu(x: torch.Tensor) -> torch.Tensor:
+    B, C, H, W = x.shape
+    cg = (C + 7) // 8
+    pad = torch.zeros(B, cg * 8, H, W)
+    pad[:, :C] = x
+    return pad.view(B, cg, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().half()
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 24, 64), (1, 196, 7, 16), (1, 96, 13, 37), (2, 13, 9, 5)])
+def test_correlation_c8_vs_oracle(dev, shape):
+    """fp16 cost volume vs the CPU oracle on the same fp16-rounded inputs (fp32 accumulation in the kernel, one
+    rounding of the result to half: 1e-3 relative)."""
+    from opticalflow_amd import ops_f16 as F16
+    from oracle import pwc_oracle as O
+    B, C, H, W = shape
+    a = seeded_rand(shape, 530, -1, 1).half().float()
+    b = seeded_rand(shape, 531, -1, 1).half().float()
+    ref = O.correlation(a, b, 4, 1, 4, 1, 1, 1)
+    got_c8 = F16.correlation_c8(F16.to_c8(a.to(dev)), F16.to_c8(b.to(dev)), C)
+    assert got_c8.shape == (B, 11, H, W, 8)
+    got = F16.from_c8(got_c8, 81).cpu()
+    assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+    assert (got_c8[:, 10, :, :, 1:] == 0).all()                                      # channels 81..87
+    gotn = F16.from_c8(F16.correlation_c8(F16.to_c8(a.to(dev)), F16.to_c8(b.to(dev)), C, normalize=True, leaky_slope=0.1), 81).cpu()
+    assert (gotn - O.leaky_relu(ref / C)).abs().max().item() <= 1e-3
+    # arena slot output
+    arena = torch.full((B, 20, H, W, 8), 3.0, dtype=torch.float16, device=dev)
+    F16.correlation_c8(F16.to_c8(a.to(dev)), F16.to_c8(b.to(dev)), C, out=arena[:, 4:15])
+    assert torch.equal(arena[:, 4:15], got_c8) and (arena[:, :4] == 3).all() and (arena[:, 15:] == 3).all()
+
+
+@pytest.mark.parametrize("align,thr", [(False, 0.9999), (True, 0.999)])
+def test_warp_c8_vs_oracle(dev, align, thr):
+    from opticalflow_amd import ops_f16 as F16
+    from oracle import pwc_oracle as O
+    B, C, H, W = 2, 21, 14, 33
+    x = seeded_rand((B, C, H, W), 540, -1, 1).half().float()
+    flo = seeded_rand((B, 2, H, W), 541, -3, 3).half().float()
+    ref = O.warp(x, flo * 1.25, align_corners=align, mask_threshold=thr)
+    flo_group = torch.zeros(B, 8, H, W)
+    flo_group[:, 2:4] = flo                                                          # (u, v) at channels 2, 3 of the group
+    got = F16.from_c8(F16.warp_c8(F16.to_c8(x.to(dev)), F16.to_c8(flo_group.to(dev)), C, flo_channel=2, flow_scale=1.25,
+                                  align_corners=align, mask_threshold=thr), C).cpu()
+    assert ((got == 0) == (ref == 0)).float().mean().item() > 0.995                 # mask decisions
+    assert (got - ref).abs().max().item() < 2e-3
+    assert torch.equal(_to_c8_cpu(x), F16.to_c8(x.to(dev)).cpu())
+
+
+def test_forward_fp16_vs_reference_golden(dev):
+    """Whole network with half-precision activations/filters (fp32 accumulation) vs the reference's fp32 output on the
+    golden inputs.  Bar: mean EPE <= 1e-2 * mean |flow|; observed ~1e-3 relative."""
+    from conftest import load_golden
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    from oracle import pwc_oracle as O
+    g = load_golden("g3_forward.npz")
+    net = PWCDCNet(precision="fp16").to(dev).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=int(g["wseed"]), gain=float(g["gain"]),
+                                             bias_std=float(g["bias_std"])))
+    for tag in ("s", "m"):
+        x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag]).to(dev)
+        f2 = net(x).cpu()
+        ref = torch.from_numpy(g["flow2_" + tag])
+        assert f2.shape == ref.shape and f2.dtype == torch.float32
+        epe, scale = O.epe(f2, ref), ref.abs().mean().item()
+        print("fp16 forward [%s]: EPE %.3e, mean|flow| %.3f" % (tag, epe, scale))
+        assert epe <= 1e-2 * scale, (tag, epe, scale)
+    eager = net(x)
+    net.use_graph = True
+    assert torch.equal(net(x), eager) and torch.equal(net(x), eager)
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(x)
+    with pytest.raises(ValueError):
+        PWCDCNet(precision="bf16")
