@@ -30,6 +30,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md: ~2.5 PF)
 GAIN, BIAS_STD = 0.85, 0.02    # synthetic-weight recipe shared with tests/golden (mean |flow2| ~ 1)
 
 
@@ -107,6 +108,73 @@ def event_time_ms(fn, reps, stream):
     return start.elapsed_time(stop) / reps
 
 
+def probes_fp32(result, args, plan, B, H, W, h2, w2, stream):
+    """roofline / roofline_corr / roofline_warp of the fp32 plan: HIP-event averages of back-to-back launches."""
+    from opticalflow_amd import ops
+    full = B == 16 and (H, W) == (448, 1024)
+    if args.conv_backend == "hip":
+        cin = plan.arena[2].shape[1]
+        flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
+        ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
+        ach = flops / (ms * 1e-3) / 1e12
+        result["roofline"] = {"kernel": "conv3x3_mfma_kernel<4, 1, 1, 1, 1, 0> = <MT,NT,stride,dilation,two-per-CU,split-K> "
+                                        "(dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
+                              "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                              "traffic": pmc_traffic("conv3x3_mfma_dc_conv1_b16", full),
+                              "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
+    c2 = 32
+    off = 448 + 81
+    ar = plan.arena[2]
+    bytes_corr = (2 * c2 + 81) * h2 * w2 * 4 * B
+    ms = event_time_ms(lambda: ops.correlation(ar[:, off:off + c2], plan.warped[2], 4, 1, 4, 1, 1, 1.0,
+                                               leaky_slope=0.1, out=ar[:, 448:529]), 20, stream)
+    gbs = bytes_corr / (ms * 1e-3) / 1e9
+    result["roofline_corr"] = {"kernel": "corr81_dma_kernel (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena write)" % (w2, h2, B),
+                               "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
+                               "traffic": pmc_traffic("corr81_level2_b16", full),
+                               "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
+    if args.conv_backend != "hip":
+        result["roofline"] = result["roofline_corr"]
+    bytes_warp = (2 * c2 + 2) * h2 * w2 * 4 * B
+    ms = event_time_ms(lambda: ops.warp(plan.c2[2], ar[:, off + c2:off + c2 + 2], 5.0, False, out=plan.warped[2]), 20, stream)
+    result["roofline_warp"] = {"kernel": "warp_kernel<f32> (level 2)", "bound": "hbm",
+                               "achieved": round(bytes_warp / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4)}
+
+
+def probes_fp16(result, plan, B, H, W, h2, w2, stream):
+    """The same three probes on the half-precision plan (c8 layout): algorithmic flops use the real 565 input
+    channels of dc_conv1 (the arena carries 576 with its zero pad channels); bytes are halves."""
+    from opticalflow_amd import ops_f16 as F16
+    from opticalflow_amd.engine_f16 import BASE_G, CORR_G
+    flops = 2.0 * 128 * 565 * 9 * h2 * w2 * B
+    ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
+    ach = flops / (ms * 1e-3) / 1e12
+    result["roofline"] = {"kernel": "conv3x3_f16_kernel<4, 1, 1, 3> = <MT,stride,dilation,ring> (dc_conv1 565->128 @%dx%d, B=%d, "
+                                    "v_mfma_f32_32x32x16_f16)" % (w2, h2, B),
+                          "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                          "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
+    ar = plan.arena[2]
+    f0 = BASE_G + CORR_G
+    c2 = 32
+    bytes_corr = (2 * c2 + 81) * h2 * w2 * 2 * B
+    ms = event_time_ms(lambda: F16.correlation_c8(ar[:, f0:f0 + 4], plan.warped[2], c2, leaky_slope=0.1,
+                                                  out=ar[:, BASE_G:BASE_G + CORR_G]), 20, stream)
+    gbs = bytes_corr / (ms * 1e-3) / 1e9
+    result["roofline_corr"] = {"kernel": "corr81_c8_kernel (level 2: C=32 @%dx%d, B=%d, f16, fused LeakyReLU, arena write)" % (w2, h2, B),
+                               "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
+                               "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
+    bytes_warp = (2 * c2 + 2) * h2 * w2 * 2 * B
+    ms = event_time_ms(lambda: F16.warp_c8(plan.pyr_a[2][B:], ar[:, f0 + 4:f0 + 5], c2, flow_scale=5.0, out=plan.warped[2]), 20, stream)
+    result["roofline_warp"] = {"kernel": "warp_c8_kernel (level 2, f16)", "bound": "hbm",
+                               "achieved": round(bytes_warp / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +184,8 @@ def main():
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--conv-backend", default="hip", choices=["hip", "torch"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+                    help="fp32 = the headline metric (BASELINE configs[2]); fp16 = half activations/filters, fp32 accumulation (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -151,7 +221,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, H, W = args.batch, args.height, args.width
-    net = PWCDCNet(conv_backend=args.conv_backend, use_graph=not args.no_graph)
+    net = PWCDCNet(conv_backend=args.conv_backend, use_graph=not args.no_graph, precision=args.precision)
     if rank == 0:
         net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=GAIN, bias_std=BIAS_STD))
     net = net.to(dev).eval()
@@ -198,23 +268,26 @@ def main():
         elapsed = float(tmax.item())
 
     result = None
+    fp32 = args.precision == "fp32"
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
         macs = conv_macs_per_pair(H, W)
         result = {
-            "metric": "image-pairs/sec at 1024x448 fp32", "value": round(value, 3), "unit": "image-pairs/s",
+            "metric": "image-pairs/sec at 1024x448 %s" % args.precision, "value": round(value, 3), "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if fp32 else "f16",
             "data": "synthetic (uniform[0,1) image pairs; seeded Kaiming-fan-in weights x0.85, no checkpoint available)",
-            "config": {"workload": "BASELINE configs[2]: batch=%d/GPU %dx%d fp32, full HIP path (corr+warp+MFMA convs)%s"
-                                   % (B, W, H, "" if args.conv_backend == "hip" else " [convs on PyTorch-ROCm: configs[1]]"),
+            "config": {"workload": ("BASELINE configs[2]: batch=%d/GPU %dx%d fp32, full HIP path (corr+warp+MFMA convs)%s"
+                                    % (B, W, H, "" if args.conv_backend == "hip" else " [convs on PyTorch-ROCm: configs[1]]")) if fp32 else
+                                   ("BASELINE configs[3] per-GPU shard: batch=%d/GPU %dx%d, fp16 activations and filters (c8 layout), "
+                                    "fp32 accumulation, fp32 input/output" % (B, W, H)),
                        "pairs_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
                        "conv_backend": args.conv_backend, "hip_graph": not args.no_graph,
                        "parallelism": "batch-shard x%d, weights broadcast %d B, flow gather to rank 0" % (world, bcast_bytes)},
             "conv_gflop_per_pair": round(2 * macs / 1e9, 3),
-            "mfma_util_whole_forward": round(2 * macs * value / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "mfma_util_whole_forward": round(2 * macs * value / 1e12 / (MFMA_F32_PEAK_TFLOPS if fp32 else MFMA_F16_PEAK_TFLOPS), 4),
         }
 
     # ---- per-kernel roofline probes (rank 0; HIP events on the launch stream) -----------------------
@@ -224,37 +297,10 @@ def main():
         plan = net._plan_for(x)
         stream = torch.cuda.current_stream(dev)
         h2, w2 = H >> 2, W >> 2
-        if args.conv_backend == "hip":
-            cin = plan.arena[2].shape[1]
-            flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
-            ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
-            ach = flops / (ms * 1e-3) / 1e12
-            result["roofline"] = {"kernel": "conv3x3_mfma_kernel<4, 1, 1, 1, 1, 0> = <MT,NT,stride,dilation,two-per-CU,split-K> "
-                                            "(dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
-                                  "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                                  "traffic": pmc_traffic("conv3x3_mfma_dc_conv1_b16", B == 16 and (H, W) == (448, 1024)),
-                                  "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
-        from opticalflow_amd import ops
-        c2 = 32
-        off = 448 + 81
-        ar = plan.arena[2]
-        bytes_corr = (2 * c2 + 81) * h2 * w2 * 4 * B
-        ms = event_time_ms(lambda: ops.correlation(ar[:, off:off + c2], plan.warped[2], 4, 1, 4, 1, 1, 1.0,
-                                                   leaky_slope=0.1, out=ar[:, 448:529]), 20, stream)
-        gbs = bytes_corr / (ms * 1e-3) / 1e9
-        result["roofline_corr"] = {"kernel": "corr81_dma_kernel (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena write)" % (w2, h2, B),
-                                   "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
-                                   "traffic": pmc_traffic("corr81_level2_b16", B == 16 and (H, W) == (448, 1024)),
-                                   "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
-        if args.conv_backend != "hip":
-            result["roofline"] = result["roofline_corr"]
-        bytes_warp = (2 * c2 + 2) * h2 * w2 * 4 * B
-        ms = event_time_ms(lambda: ops.warp(plan.c2[2], ar[:, off + c2:off + c2 + 2], 5.0, False, out=plan.warped[2]), 20, stream)
-        result["roofline_warp"] = {"kernel": "warp_kernel<f32> (level 2)", "bound": "hbm",
-                                   "achieved": round(bytes_warp / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4)}
+        if fp32:
+            probes_fp32(result, args, plan, B, H, W, h2, w2, stream)
+        else:
+            probes_fp16(result, plan, B, H, W, h2, w2, stream)
 
         # ---- parity spot check + CPU baseline (the oracle is the checker / the baseline, never the product)
         log("roofline probes done; parity spot check")
