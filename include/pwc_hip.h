@@ -131,6 +131,12 @@ int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
 int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
 int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
 
+/* First pyramid layer (conv1a: Conv2d(3,16,3,stride 2,pad 1) + LeakyReLU, PWCNet.py:52) from a float32 NCHW image
+ * x:[B,3,H,W] (batch stride free: a pair tensor [B,6,H,W] is two calls) straight to c8 halves y:[B,2,H/2,W/2,8];
+ * w:[16,3,3,3] f32 (nn layout), bias:[16] f32. */
+int pwc_image_conv_s2_c8_f16(const void *x, const void *w, const void *bias, void *y, int B, int H, int W,
+                             float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream);
+
 /* PWC-Net's cost volume (pad 4, kernel 1, max displacement 4, strides 1) on c8 f16 tensors, fp32 accumulation:
  * in1,in2: [B][ceil(C/8)][H][W][8]; out: [B][11][H][W][8] = 81 displacement channels ((dy+4)*9+(dx+4)) + 7 zeros.
  * flags: PWC_CORR_NORMALIZE (divide by C instead of multiplying by corr_multiply), PWC_ACT_LEAKY. */

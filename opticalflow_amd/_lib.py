@@ -44,6 +44,8 @@ SIGNATURES = {
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),
     "pwc_nchw_to_c8_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_c8_f16_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "pwc_image_conv_s2_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                         c_int64, c_int64, c_void_p]),
     "pwc_corr81_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint, c_float,
                                   c_int64, c_int64, c_int64, c_void_p]),
     "pwc_warp_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float,

@@ -269,7 +269,11 @@ int launch16(const Args16 &a) {
         auto kern = conv3x3_f16_kernel<MT, S, D, R>;
         static pwc::LdsAttrOnce attr;
         if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), G::kSmem, a.stream,
+        // short-K layers (pyramid level 1: one or two chunks) only need as many ring slots as they have chunks: the
+        // smaller LDS footprint lets several workgroups share a CU and cover each other's single DMA round trip
+        const int nchunks = (a.Cg + 1) / 2;
+        const int smem = (nchunks < R ? nchunks : R) * G::kSlotBytes;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), smem, a.stream,
                            a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo, tiles_x, tiles_y,
                            a.bsx, a.bsy, a.slope, a.do_leaky);
         return pwc::check_launch("conv3x3_f16_kernel");

@@ -165,7 +165,68 @@ warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo,
     }
 }
 
+// ---- first pyramid layer ----------------------------------------------------------------------------------------
+// conv1a (3 -> 16, stride 2, pad 1) + LeakyReLU straight from the float32 NCHW image to c8 halves: with K = 27 the MFMA
+// kernel is pure per-workgroup overhead (324 us at batch 16 + 106 us of layout conversion); here one thread computes
+// the 16 channels of one output pixel from its 3x3x3 window (432 fma), weights broadcast from LDS.
+__global__ void __launch_bounds__(256)
+image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                     _Float16 *__restrict__ y, int H, int W, int Ho, int Wo, int64_t npix, int64_t bsx, int64_t bsy,
+                     float slope) {
+    __shared__ float sw[27][16];
+    __shared__ float sb[16];
+    for (int i = threadIdx.x; i < 27 * 16; i += 256) sw[i / 16][i % 16] = w[(i % 16) * 27 + i / 16];   // w[co][ci][ky][kx]
+    if (threadIdx.x < 16) sb[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int64_t oplane = (int64_t)Ho * Wo;
+    const int b = (int)(i / oplane);
+    const int pix = (int)(i - (int64_t)b * oplane);
+    const int oy = pix / Wo, ox = pix - oy * Wo;
+    float acc[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc[co] = sb[co];
+    const float *xb = x + (int64_t)b * bsx;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((int64_t)ci * H + iy) * W + ix] : 0.f;
+                const float *wr = sw[(ci * 3 + ky) * 3 + kx];
+#pragma unroll
+                for (int co = 0; co < 16; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+            }
+        }
+    _Float16 *yo = y + (int64_t)b * bsy + (int64_t)pix * 8;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)pwc::leaky(acc[g * 8 + j], slope);
+        *reinterpret_cast<h8 *>(yo + (int64_t)g * oplane * 8) = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int pwc_image_conv_s2_c8_f16(const void *x, const void *w, const void *bias, void *y, int B, int H, int W,
+                                        float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
+    if (!x || !w || !bias || !y || B <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_image_conv_s2_c8_f16: bad argument");
+    if (!pwc::aligned16(y) || (y_bstride % 8)) PWC_FAIL(PWC_EALIGN, "pwc_image_conv_s2_c8_f16: output must be 16-byte aligned");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t npix = (int64_t)B * Ho * Wo;
+    const int64_t nblk = (npix + 255) / 256;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_image_conv_s2_c8_f16: grid too large");
+    hipLaunchKernelGGL(image_conv_s2_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(x), static_cast<const float *>(w), static_cast<const float *>(bias),
+                       static_cast<_Float16 *>(y), H, W, Ho, Wo, npix, x_bstride, y_bstride, leaky_slope);
+    return pwc::check_launch("image_conv_s2_kernel");
+}
 
 extern "C" int pwc_corr81_c8_f16(const void *in1, const void *in2, void *out, int B, int C, int H, int W,
                                  float corr_multiply, unsigned flags, float leaky_slope,

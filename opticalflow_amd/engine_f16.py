@@ -76,7 +76,6 @@ class PwcPlanF16:
         self.nd = 81
         hk = dict(device=device, dtype=torch.float16)
         self.size = {l: (H >> l, W >> l) for l in range(1, 7)}
-        self.img = torch.zeros((2 * B, 1, H, W, 8), **hk)
         self.pyr_a, self.pyr_b = {}, {}
         for l in range(1, 7):
             h, w = self.size[l]
@@ -110,11 +109,15 @@ class PwcPlanF16:
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
 
         p = {k: v.detach().float() for k, v in params.items()}
+        # conv1a (3 -> 16, stride 2) runs straight from the float32 image (ops_f16.image_conv_s2): keep its raw filters
+        self.w1a = p["conv1a.0.weight"].contiguous()
+        self.b1a = p["conv1a.0.bias"].contiguous()
         for l, names in enumerate(PYRAMID_NAMES, start=1):
             for i, n in enumerate(names):
+                if l == 1 and i == 0:
+                    continue
                 w = p[n + ".0.weight"]
-                phys = 8 if (l == 1 and i == 0) else _groups(w.shape[1]) * 8
-                put(n, _pad_cin(w, phys), p[n + ".0.bias"])
+                put(n, _pad_cin(w, _groups(w.shape[1]) * 8), p[n + ".0.bias"])
         for l in range(2, 7):
             full = _phys_index(l)
             nphys = int(self.arena[l].shape[1]) * 8
@@ -167,13 +170,15 @@ class PwcPlanF16:
         if tuple(x.shape) != (B, 6, self.H, self.W) or x.dtype != torch.float32 or x.device != self.device:
             raise ValueError("plan built for float32 %s on %s, got %s %s on %s" % (
                 (B, 6, self.H, self.W), self.device, x.dtype, tuple(x.shape), x.device))
-        F16.to_c8(x[:, :3], out=self.img[:B])
-        F16.to_c8(x[:, 3:], out=self.img[B:])
-        prev = self.img
+        prev = None
         for l in range(1, 7):
             na, naa, nb = PYRAMID_NAMES[l - 1]
             a, bb = self.pyr_a[l], self.pyr_b[l]
-            self._conv(na, prev, a, stride=2)
+            if l == 1:
+                F16.image_conv_s2(x[:, :3], self.w1a, self.b1a, LEAKY, out=a[:B])
+                F16.image_conv_s2(x[:, 3:], self.w1a, self.b1a, LEAKY, out=a[B:])
+            else:
+                self._conv(na, prev, a, stride=2)
             self._conv(naa, a, bb)
             self._conv(nb, bb, a)
             prev = a

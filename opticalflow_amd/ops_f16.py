@@ -150,3 +150,26 @@ def warp_c8(x: torch.Tensor, flo: torch.Tensor, channels: int, flo_channel: int 
                                  float(flow_scale), 1 if align_corners else 0, float(mask_threshold), bsx, bsf, bso, _stream(x))
     check(rc, "pwc_warp_c8_f16")
     return out
+
+
+def image_conv_s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, leaky_slope: float = 0.1,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv1a (Conv2d(3,16,3,stride 2,pad 1) + LeakyReLU) from a float32 [B,3,H,W] image (dense planes, free batch
+    stride) to c8 halves [B,2,H/2,W/2,8]; weight [16,3,3,3] / bias [16] float32."""
+    _require_device(x, "x")
+    if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x[0].is_contiguous():
+        raise ValueError("x must be float32 [B,3,H,W] with dense planes")
+    if tuple(weight.shape) != (16, 3, 3, 3) or weight.dtype != torch.float32 or not weight.is_contiguous() or bias.numel() != 16:
+        raise ValueError("weight must be contiguous float32 [16,3,3,3] and bias [16]")
+    B, _, H, W = x.shape
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B, 2, ho, wo, 8), dtype=torch.float16, device=x.device)
+    elif tuple(out.shape) != (B, 2, ho, wo, 8):
+        raise ValueError("out must be %s" % ((B, 2, ho, wo, 8),))
+    bso = _c8_bstride(out, "out")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pwc_image_conv_s2_c8_f16(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+                                                  float(leaky_slope), x.stride(0) if B > 1 else 3 * H * W, bso, _stream(x))
+    check(rc, "pwc_image_conv_s2_c8_f16")
+    return out

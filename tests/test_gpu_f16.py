@@ -174,3 +174,17 @@ def test_forward_fp16_vs_reference_golden(dev):
         net(x)
     with pytest.raises(ValueError):
         PWCDCNet(precision="bf16")
+
+
+def test_image_conv_s2_vs_torch(dev):
+    """conv1a straight from the float32 image (pair tensor halves are batch-strided views) to c8 halves."""
+    from opticalflow_amd import ops_f16 as F16
+    x = seeded_rand((2, 6, 37, 70), 550, 0, 1)
+    w = seeded_rand((16, 3, 3, 3), 551, -1, 1) * 0.3
+    b = seeded_rand((16,), 552, -0.5, 0.5)
+    xd = x.to(dev)
+    for half in (slice(0, 3), slice(3, 6)):
+        ref = F.leaky_relu(F.conv2d(x[:, half].double(), w.double(), b.double(), stride=2, padding=1), 0.1)
+        got = F16.from_c8(F16.image_conv_s2(xd[:, half], w.to(dev), b.to(dev)), 16).cpu().double()
+        assert got.shape == ref.shape == (2, 16, 19, 35)
+        assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
