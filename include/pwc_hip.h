@@ -126,10 +126,7 @@ int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout);
 int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream);
 int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
                        int B, int Cin, int H, int W, int Cout, int stride, int dilation,
-                       unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride,
-                       void *workspace, int64_t workspace_bytes, void *stream);
-/* split-K scratch of the fp16 convolution (same contract as pwc_conv2d_workspace_bytes; partial sums are fp32) */
-int64_t pwc_conv2d_f16_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation);
+                       unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream);
 /* layout conversions at the edges of an fp16 pipeline: NCHW f32 <-> c8 f16 (batch strides in elements) */
 int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
 int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);

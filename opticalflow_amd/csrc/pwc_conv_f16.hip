@@ -26,7 +26,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kBlock = 320;          // waves 0..3: MFMA, wave 4: loader (a second loader wave measured no gain)
+constexpr int kBlock = 320;          // waves 0..3: MFMA, wave 4: loader
 constexpr int kTileW = 32;
 constexpr int kNT = 2;               // rows per wave -> 8-row tiles
 constexpr unsigned kOOB = 0x80000000u;
@@ -55,27 +55,23 @@ struct G16 {
 
 // loader wave: start the LDS-DMA of one 16-channel chunk (input halo tile, then the filter slab) into its ring slot
 template <class G>
-__device__ __forceinline__ void issue_f16(const _Float16 *xb, const _Float16 *wp, int chunk, int slot, int Cg, int plane,
-                                          int CoutP, unsigned char *smem, const unsigned *off) {
+__device__ __forceinline__ void issue_f16(const _Float16 *xb, const _Float16 *wp, int chunk, int Cg, int plane, int CoutP,
+                                          unsigned char *smem, const unsigned *off) {
     const int cgv = min(2, Cg - 2 * chunk);               // ragged last pair: kh = 1 is range-checked to zero
     const pwc::v4i32 rin = pwc::make_rsrc(xb + (int64_t)chunk * 2 * plane * 8, cgv * plane * 16);
     const pwc::v4i32 rw = pwc::make_rsrc(wp + (int64_t)chunk * 18 * CoutP * 8, 18 * CoutP * 16);
-    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(smem + slot * G::kSlotBytes));
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(smem + (chunk % G::kRing) * G::kSlotBytes));
 #pragma unroll
     for (int i = 0; i < G::kInInstr; ++i) pwc::dma_b128(rin, base + i * 1024, off[i]);
 #pragma unroll
     for (int i = 0; i < G::kWInstr; ++i) pwc::dma_b128(rw, base + G::kWOffBytes + i * 1024, off[G::kInInstr + i]);
 }
 
-// SPLIT = 1 (split-K, layers with few output tiles and many input channels: pyramid levels 6-4): blockIdx.z owns the
-// chunk range [z*cps, (z+1)*cps) and writes raw fp32 partial sums to `partial` [z][b][CoutP][Ho][Wo];
-// splitk_reduce_c8_kernel adds them in fixed z order, applies bias / LeakyReLU and writes the c8 halves.
-template <int MT, int S, int D, int R, int SPLIT>
+template <int MT, int S, int D, int R>
 __global__ void __launch_bounds__(kBlock)
 conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp, const float *__restrict__ bias,
                    _Float16 *__restrict__ y, int Cg, int H, int W, int Cout, int CoutP, int Ho, int Wo,
-                   int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int do_leaky,
-                   float *__restrict__ partial, int cps, int nbatch) {
+                   int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int do_leaky) {
     using G = G16<MT, S, D, R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -91,12 +87,7 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     const int ox0 = tx * kTileW;
     const int oy0 = ty * G::kTileH;
     const int plane = H * W;
-    int c_lo = 0, c_hi = (Cg + 1) / 2;
-    if constexpr (SPLIT) {
-        c_lo = (int)blockIdx.z * cps;                          // the host guarantees c_lo < (Cg+1)/2
-        c_hi = min(c_hi, c_lo + cps);
-    }
-    const int nchunks = c_hi - c_lo;                           // chunks of THIS workgroup; ring slots count from c_lo
+    const int nchunks = (Cg + 1) / 2;
     const _Float16 *xb = x + (int64_t)b * bsx;
 
     if (wave == 4) {
@@ -121,14 +112,14 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
             const int co = g * G::kCoutT + q % G::kCoutT;
             off[G::kInInstr + i] = (q < G::kWPieces && co < CoutP) ? (unsigned)(row * CoutP + co) * 16u : kOOB;
         }
-        issue_f16<G>(xb, wp, c_lo, 0, Cg, plane, CoutP, smem, off);
-        if (R == 3 && nchunks > 1) issue_f16<G>(xb, wp, c_lo + 1, 1, Cg, plane, CoutP, smem, off);
+        issue_f16<G>(xb, wp, 0, Cg, plane, CoutP, smem, off);
+        if (R == 3 && nchunks > 1) issue_f16<G>(xb, wp, 1, Cg, plane, CoutP, smem, off);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             // chunk has landed; with R == 3 the next one may stay in flight
             if (R == 3 && chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::kInstr) : "memory");
             else                               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // consumers may read slot chunk%R; they are done with (chunk-1)%R
-            if (chunk + R - 1 < nchunks) issue_f16<G>(xb, wp, c_lo + chunk + R - 1, (chunk + R - 1) % R, Cg, plane, CoutP, smem, off);
+            if (chunk + R - 1 < nchunks) issue_f16<G>(xb, wp, chunk + R - 1, Cg, plane, CoutP, smem, off);
         }
         return;
     }
@@ -142,7 +133,7 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-            const float bv = SPLIT ? 0.f : bias[min(co, Cout - 1)];
+            const float bv = bias[min(co, Cout - 1)];
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) acc[mt][nt][j] = bv;
         }
@@ -179,17 +170,6 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     for (int nt = 0; nt < kNT; ++nt) {
         const int oy = oy0 + wave * kNT + nt;
         if (oy >= Ho || ox >= Wo) continue;
-        if constexpr (SPLIT) {
-            float *pz = partial + (((int64_t)blockIdx.z * nbatch + b) * CoutP) * oplane + (int64_t)oy * Wo + ox;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-                    if (co < CoutP) pz[(int64_t)co * oplane] = acc[mt][nt][j];
-                }
-            continue;
-        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -207,32 +187,6 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
             }
         }
     }
-}
-
-// y(c8 half) = act(bias + sum_z partial[z]) : one thread per (image, output group, pixel), fixed z order
-__global__ void __launch_bounds__(256)
-splitk_reduce_c8_kernel(const float *__restrict__ partial, const float *__restrict__ bias, _Float16 *__restrict__ y,
-                        int Cout, int CoutP, int cg_out, int64_t oplane, int64_t total, int ksplit, int nbatch, int64_t bsy,
-                        float slope, int do_leaky) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int64_t pix = i % oplane;
-    int64_t t = i / oplane;
-    const int cg = (int)(t % cg_out);
-    const int64_t b = t / cg_out;
-    h8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int co = cg * 8 + j;
-        float v = 0.f;
-        if (co < Cout) {
-            v = bias[co];
-            for (int z = 0; z < ksplit; ++z) v += partial[(((int64_t)z * nbatch + b) * CoutP + co) * oplane + pix];
-            if (do_leaky) v = pwc::leaky(v, slope);
-        }
-        o[j] = (_Float16)v;
-    }
-    *reinterpret_cast<h8 *>(y + b * bsy + ((int64_t)cg * oplane + pix) * 8) = o;
 }
 
 // wp[cgp][tap][kh][CoutP][8] <- w[co][ci = 8*(2*cgp + kh) + j][tap]   (zero outside Cin / Cout)
@@ -299,25 +253,7 @@ struct Args16 {
     float slope;
     int do_leaky;
     hipStream_t stream;
-    float *partial = nullptr;           // split-K workspace (fp32 [ksplit][B][CoutP][Ho][Wo]) or null
-    int ksplit = 1, cps = 0;
 };
-
-// split-K plan shared by pwc_conv2d_f16_fwd and pwc_conv2d_f16_workspace_bytes (stride 1, dilation 1, 8x32 tile, MT = 1..4)
-struct Split16 { int ksplit, cps; };
-inline Split16 plan_split16(int B, int Cg, int Ho, int Wo, int CoutP) {
-    static const int knob = [] { const char *e = getenv("PWC_CONV16F_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
-    const int t32 = CoutP / 32;
-    const int groups = (t32 + 3) / 4;
-    const int64_t blocks = (int64_t)B * ((Wo + kTileW - 1) / kTileW) * ((Ho + 7) / 8) * groups;
-    const int nchunks = (Cg + 1) / 2;
-    if (knob == 0 || blocks > 128 || nchunks < 6) return {1, nchunks};
-    int ks = knob > 0 ? knob : (int)((256 + blocks - 1) / blocks);
-    ks = min(ks, nchunks / 2);
-    if (ks < 2) return {1, nchunks};
-    const int cps = (nchunks + ks - 1) / ks;
-    return {(nchunks + cps - 1) / cps, cps};
-}
 
 template <int MT, int S, int D, int R>
 int launch16(const Args16 &a) {
@@ -330,25 +266,7 @@ int launch16(const Args16 &a) {
         const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
         const int groups = (a.CoutP / 32 + MT - 1) / MT;
         if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
-        if constexpr (S == 1 && D == 1 && R == 3) {
-            if (a.ksplit > 1) {
-                auto kern = conv3x3_f16_kernel<MT, S, D, R, 1>;
-                static pwc::LdsAttrOnce attr_s;
-                if (const int rc = pwc::ensure_lds_attr(attr_s, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
-                const int smem = (a.cps < R ? a.cps : R) * G::kSlotBytes;
-                hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups, (unsigned)a.ksplit), dim3(kBlock), smem, a.stream,
-                                   a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo, tiles_x, tiles_y,
-                                   a.bsx, a.bsy, a.slope, a.do_leaky, a.partial, a.cps, a.B);
-                if (const int rc = pwc::check_launch("conv3x3_f16_kernel<split>")) return rc;
-                const int cg_out = (a.Cout + 7) / 8;
-                const int64_t oplane = (int64_t)a.Ho * a.Wo, total = (int64_t)a.B * cg_out * oplane;
-                hipLaunchKernelGGL(splitk_reduce_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a.stream,
-                                   a.partial, a.bias, a.y, a.Cout, a.CoutP, cg_out, oplane, total, a.ksplit, a.B, a.bsy,
-                                   a.slope, a.do_leaky);
-                return pwc::check_launch("splitk_reduce_c8_kernel");
-            }
-        }
-        auto kern = conv3x3_f16_kernel<MT, S, D, R, 0>;
+        auto kern = conv3x3_f16_kernel<MT, S, D, R>;
         static pwc::LdsAttrOnce attr;
         if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
         // short-K layers (pyramid level 1: one or two chunks) only need as many ring slots as they have chunks: the
@@ -357,7 +275,7 @@ int launch16(const Args16 &a) {
         const int smem = (nchunks < R ? nchunks : R) * G::kSlotBytes;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), smem, a.stream,
                            a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo, tiles_x, tiles_y,
-                           a.bsx, a.bsy, a.slope, a.do_leaky, (float *)nullptr, 0, a.B);
+                           a.bsx, a.bsy, a.slope, a.do_leaky);
         return pwc::check_launch("conv3x3_f16_kernel");
     }
 }
@@ -390,13 +308,6 @@ extern "C" int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return -1;
     const int cg = (Cin + 7) / 8;
     return (int64_t)((cg + 1) / 2) * 18 * cout_padded(Cout) * 16;
-}
-
-extern "C" int64_t pwc_conv2d_f16_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation) {
-    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return -1;
-    if (stride != 1 || dilation != 1) return 0;
-    const Split16 sp = plan_split16(B, (Cin + 7) / 8, H, W, cout_padded(Cout));
-    return sp.ksplit > 1 ? (int64_t)sp.ksplit * B * cout_padded(Cout) * H * W * 4 : 0;
 }
 
 extern "C" int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream) {
@@ -433,8 +344,7 @@ extern "C" int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, i
 
 extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
                                   int B, int Cin, int H, int W, int Cout, int stride, int dilation,
-                                  unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride,
-                                  void *workspace, int64_t workspace_bytes, void *stream) {
+                                  unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
     if (!x || !wp || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: null pointer");
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: bad shape");
     if (!pwc::aligned16(x) || !pwc::aligned16(y) || !pwc::aligned16(wp) || (x_bstride % 8) || (y_bstride % 8))
@@ -456,14 +366,6 @@ extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bia
     a.slope = leaky_slope;
     a.do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
     a.stream = static_cast<hipStream_t>(stream);
-    if (stride == 1 && dilation == 1 && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 3u)) {
-        const Split16 sp = plan_split16(B, cg, a.Ho, a.Wo, a.CoutP);
-        if (sp.ksplit > 1 && workspace_bytes >= (int64_t)sp.ksplit * B * a.CoutP * plane * 4) {
-            a.partial = static_cast<float *>(workspace);
-            a.ksplit = sp.ksplit;
-            a.cps = sp.cps;
-        }
-    }
     if (stride == 1) {
         switch (dilation) {
             case 1: return dispatch16<1, 1>(a);

@@ -103,14 +103,10 @@ class PwcPlanF16:
         self.cin: Dict[str, int] = {}
         self.cout: Dict[str, int] = {}
 
-        self._ws_need = 0
-
-        def put(name, w, bias, geom=None):
+        def put(name, w, bias):
             self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float())
             self.b[name] = bias.contiguous().float()
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
-            if geom is not None:                     # (batch, h, w) of a stride-1 dilation-1 layer: split-K scratch it may want
-                self._ws_need = max(self._ws_need, F16.conv3x3_f16_workspace_bytes(geom[0], w.shape[1], geom[1], geom[2], w.shape[0]))
 
         p = {k: v.detach().float() for k, v in params.items()}
         # conv1a (3 -> 16, stride 2) runs straight from the float32 image (ops_f16.image_conv_s2): keep its raw filters
@@ -121,7 +117,7 @@ class PwcPlanF16:
                 if l == 1 and i == 0:
                     continue
                 w = p[n + ".0.weight"]
-                put(n, _pad_cin(w, _groups(w.shape[1]) * 8), p[n + ".0.bias"], None if i == 0 else (2 * B,) + self.size[l])
+                put(n, _pad_cin(w, _groups(w.shape[1]) * 8), p[n + ".0.bias"])
         for l in range(2, 7):
             full = _phys_index(l)
             nphys = int(self.arena[l].shape[1]) * 8
@@ -135,8 +131,7 @@ class PwcPlanF16:
 
             ref_start = 448                                      # conv_0 reads corr.. ; each next conv one more dense output
             for i, co in enumerate(DENSE_OUT):
-                put("conv%d_%d" % (l, i), remap(p["conv%d_%d.0.weight" % (l, i)], ref_start, ref_start), p["conv%d_%d.0.bias" % (l, i)],
-                    (B,) + self.size[l])
+                put("conv%d_%d" % (l, i), remap(p["conv%d_%d.0.weight" % (l, i)], ref_start, ref_start), p["conv%d_%d.0.bias" % (l, i)])
                 ref_start -= co
             assert ref_start == 0 and od + 448 == full.numel()
             wh, bh = p["predict_flow%d.weight" % l], p["predict_flow%d.bias" % l]
@@ -147,7 +142,7 @@ class PwcPlanF16:
                 bias = bh.new_zeros(16)
                 bias[0:2] = bh
                 bias[8:16] = p["upfeat%d.bias" % l].repeat_interleave(4)
-                put("head%d" % l, remap(k, 0, 0), bias, (B,) + self.size[l])
+                put("head%d" % l, remap(k, 0, 0), bias)
                 wd = _deconv_as_conv3x3(p["deconv%d.weight" % l])            # [8, 2, 3, 3]
                 put("deconv%d" % l, _pad_cin(wd, 8), p["deconv%d.bias" % l].repeat_interleave(4))
             else:
@@ -157,13 +152,11 @@ class PwcPlanF16:
             w = p["dc_conv%d.0.weight" % i]
             put("dc_conv%d" % i, _pad_cin(w, _groups(w.shape[1]) * 8), p["dc_conv%d.0.bias" % i])
         put("dc_conv7", _pad_cin(p["dc_conv7.weight"], 32), p["dc_conv7.bias"])
-        # one split-K scratch shared by all layers (they run back to back on one stream)
-        self.workspace = torch.empty((self._ws_need // 4,), device=device, dtype=torch.float32) if self._ws_need else None
 
     # ---- primitives -------------------------------------------------------------------------------------------------
     def _conv(self, name, x, out, stride=1, dilation=1, act=True):
         F16.conv3x3_f16(x, self.w[name], self.b[name], self.cin[name], self.cout[name], stride=stride, dilation=dilation,
-                        leaky_slope=LEAKY if act else None, out=out, workspace=self.workspace)
+                        leaky_slope=LEAKY if act else None, out=out)
 
     @staticmethod
     def _shuffle(phases: torch.Tensor, dst: torch.Tensor) -> None:

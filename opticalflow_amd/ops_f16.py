@@ -85,10 +85,8 @@ def pack_conv3x3_f16(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_f16(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cin: int, cout: int, stride: int = 1,
-                dilation: int = 1, leaky_slope: Optional[float] = 0.1, out: Optional[torch.Tensor] = None,
-                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """3x3 convolution (padding = dilation) + bias (+ LeakyReLU) on c8 float16 activations, fp32 accumulation.
-    `workspace` (device scratch, see conv3x3_f16_workspace_bytes) enables the split-K route of small layers."""
+                dilation: int = 1, leaky_slope: Optional[float] = 0.1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 convolution (padding = dilation) + bias (+ LeakyReLU) on c8 float16 activations, fp32 accumulation."""
     lib = _lib.load()
     bsx = _c8_bstride(x, "x")
     B, cg, H, W, _ = x.shape
@@ -105,24 +103,12 @@ def conv3x3_f16(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cin:
         raise ValueError("packed filters do not match Cin=%d Cout=%d" % (cin, cout))
     if bias.dtype != torch.float32 or bias.numel() != cout or bias.device != x.device or not bias.is_contiguous():
         raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
-    ws_ptr, ws_bytes = 0, 0
-    if workspace is not None:
-        if workspace.device != x.device or not workspace.is_contiguous():
-            raise ValueError("workspace must be a contiguous tensor on %s" % x.device)
-        ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     with torch.cuda.device(x.device):
         rc = lib.pwc_conv2d_f16_fwd(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout,
                                     stride, dilation, FLAG_ACT_LEAKY if leaky_slope is not None else 0,
-                                    float(leaky_slope or 0.0), bsx, bsy, ws_ptr, ws_bytes, _stream(x))
+                                    float(leaky_slope or 0.0), bsx, bsy, _stream(x))
     check(rc, "pwc_conv2d_f16_fwd")
     return out
-
-
-def conv3x3_f16_workspace_bytes(B: int, cin: int, H: int, W: int, cout: int, stride: int = 1, dilation: int = 1) -> int:
-    n = _lib.load().pwc_conv2d_f16_workspace_bytes(B, cin, H, W, cout, stride, dilation)
-    if n < 0:
-        raise ValueError("bad conv geometry")
-    return int(n)
 
 
 def correlation_c8(in1: torch.Tensor, in2: torch.Tensor, channels: int, corr_multiply: float = 1.0, normalize: bool = False,

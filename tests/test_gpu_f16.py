@@ -188,25 +188,3 @@ def test_image_conv_s2_vs_torch(dev):
         got = F16.from_c8(F16.image_conv_s2(xd[:, half], w.to(dev), b.to(dev)), 16).cpu().double()
         assert got.shape == ref.shape == (2, 16, 19, 35)
         assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.parametrize("case", [(1, 504, 32, 7, 16), (2, 565, 128, 14, 32), (1, 1016, 16, 14, 32), (16, 416, 96, 7, 16)])
-def test_conv3x3_f16_split_k(dev, case):
-    """few output tiles + long Cin: split-K route (fp32 partial sums + fixed-order reduction) when a workspace is given."""
-    from opticalflow_amd import ops_f16 as F16
-    B, cin, cout, H, W = case
-    need = F16.conv3x3_f16_workspace_bytes(B, cin, H, W, cout)
-    assert need > 0 and F16.conv3x3_f16_workspace_bytes(16, 565, 112, 256, 128) == 0
-    x = seeded_rand((B, cin, H, W), 560, -1, 1).half().float()
-    w = (seeded_rand((cout, cin, 3, 3), 561, -1, 1) * (2.0 / (cin * 9)) ** 0.5).half().float()
-    bias = seeded_rand((cout,), 562, -0.5, 0.5)
-    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), bias.double(), padding=1), 0.1)
-    xc, wp = F16.to_c8(x.to(dev)), F16.pack_conv3x3_f16(w.to(dev))
-    ws = torch.empty((need // 4,), device=dev)
-    yc = F16.conv3x3_f16(xc, wp, bias.to(dev), cin, cout, workspace=ws)
-    got = F16.from_c8(yc, cout).cpu().double()
-    assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
-    unsplit = F16.conv3x3_f16(xc, wp, bias.to(dev), cin, cout)
-    assert (yc.float() - unsplit.float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
-    assert torch.equal(F16.conv3x3_f16(xc, wp, bias.to(dev), cin, cout, workspace=ws), yc)          # deterministic
-    assert torch.equal(F16.conv3x3_f16(xc, wp, bias.to(dev), cin, cout, workspace=ws[:8]), unsplit)   # too small -> unsplit
