@@ -39,6 +39,23 @@ rocprofv3 --kernel-trace --stats -d "$OUT/prof_corr" -o corr --output-format csv
 cp "$(find "$OUT/prof_corr" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_corr.csv"
 rm -rf "$OUT/prof_corr"
 
+say "fp16 path: bench lines, kernel stats, timeline, PMC of the dominant kernel"
+python3 "$ROOT/bench.py" --precision fp16 > "$OUT/f16_bench_b16.json" 2> "$OUT/f16_bench_b16.stderr.log"
+for b in 1 32; do
+  python3 "$ROOT/bench.py" --precision fp16 --batch $b --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/f16_bench_b$b.json" 2> /dev/null
+done
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_f16" -o f16 --output-format csv -- python3 "$ROOT/bench.py" --precision fp16 --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/prof_f16.log" 2>&1
+f=$(find "$OUT/prof_f16" -name "*kernel_trace.csv" | head -1)
+python3 "$ROOT/tools/timeline.py" "$f" --full > "$OUT/f16_forward_timeline_b16.txt"
+cp "$(find "$OUT/prof_f16" -name "*kernel_stats.csv" | head -1)" "$OUT/f16_kernel_stats_bench_b16.csv"
+rm -rf "$OUT/prof_f16"
+python3 "$ROOT/tools/bench_conv_f16.py" > "$OUT/f16_microbench_conv.txt" 2>&1
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_f16_$c" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/pmc_f16_$c" conv3x3_f16 $c >> "$OUT/f16_pmc_summary.txt"
+  rm -rf "$OUT/pmc_f16_$c"
+done
+
 say "PMC passes (one counter per run)"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_dc1_$c" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv.py" dc_conv1 > /dev/null 2>&1
