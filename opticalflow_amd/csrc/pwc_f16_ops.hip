@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256)
 image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                      _Float16 *__restrict__ y, int H, int W, int Ho, int Wo, int64_t npix, int64_t bsx, int64_t bsy,
                      float slope) {
-    __shared__ float sw[27][16];
+    __shared__ __attribute__((aligned(16))) float sw[27][16];
     __shared__ float sb[16];
     for (int i = threadIdx.x; i < 27 * 16; i += 256) sw[i / 16][i % 16] = w[(i % 16) * 27 + i / 16];   // w[co][ci][ky][kx]
     if (threadIdx.x < 16) sb[threadIdx.x] = bias[threadIdx.x];
@@ -197,9 +197,15 @@ image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, c
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = 2 * ox - 1 + kx;
                 const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((int64_t)ci * H + iy) * W + ix] : 0.f;
-                const float *wr = sw[(ci * 3 + ky) * 3 + kx];
+                const float4 *wr = reinterpret_cast<const float4 *>(sw[(ci * 3 + ky) * 3 + kx]);      // 4 broadcast b128 reads
 #pragma unroll
-                for (int co = 0; co < 16; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 wq = wr[q];
+                    acc[4 * q + 0] = fmaf(v, wq.x, acc[4 * q + 0]);
+                    acc[4 * q + 1] = fmaf(v, wq.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(v, wq.z, acc[4 * q + 2]);
+                    acc[4 * q + 3] = fmaf(v, wq.w, acc[4 * q + 3]);
+                }
             }
         }
     _Float16 *yo = y + (int64_t)b * bsy + (int64_t)pix * 8;

@@ -19,7 +19,7 @@ def short(n):
     m = re.search(r"conv3x3_f16_kernel<(\d+), (\d+), (\d+), (\d+)>", n) or re.search(r"conv3x3_f16_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
     if m:
         return "f16conv<MT%s,S%s,D%s,R%s>" % m.groups()
-    for k in ("corr81_c8", "warp_c8", "nchw_to_c8", "c8_to_nchw"):
+    for k in ("corr81_c8", "warp_c8", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
         if k in n:
             return k
     for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "splitk_reduce", "warp_kernel", "copyBuffer", "elementwise", "pack3x3"):
@@ -36,8 +36,8 @@ def main():
             min_grid = int(a.split("=")[1])
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
-    if any(n == "nchw_to_c8" for n in names):      # fp16 plan: a forward starts with the two image layout conversions
-        starts = [i for i in range(len(rows) - 1) if names[i] == "nchw_to_c8" and names[i + 1] == "nchw_to_c8"
+    if any(n == "image_conv_s2" for n in names):   # fp16 plan: a forward starts with conv1a on the two images
+        starts = [i for i in range(len(rows) - 1) if names[i] == "image_conv_s2" and names[i + 1] == "image_conv_s2"
                   and int(rows[i]["Grid_Size_X"]) > min_grid]
         rows_ok = True
     else:
