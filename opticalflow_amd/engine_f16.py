@@ -162,7 +162,8 @@ class PwcPlanF16:
     def _shuffle(phases: torch.Tensor, dst: torch.Tensor) -> None:
         """phases [B,h,w,8] (channel = co*4 + py*2 + px) -> dst [B,2h,2w,2] (strided view into a flow group)."""
         B, h, w, _ = phases.shape
-        dst.copy_(phases.view(B, h, w, 2, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * h, 2 * w, 2))
+        # one strided copy: dst[b, 2y+py, 2x+px, co] = phases[b, y, x, co, py, px]
+        dst.view(B, h, 2, w, 2, 2).copy_(phases.view(B, h, w, 2, 2, 2).permute(0, 1, 4, 2, 5, 3))
 
     # ---- the forward ----------------------------------------------------------------------------------------------------
     def run(self, x: torch.Tensor) -> torch.Tensor:
@@ -214,6 +215,6 @@ class PwcPlanF16:
         self._conv("dc_conv7", t, self.dc7, act=False)
         # flow2 = predict_flow2 + dc_conv7 (PWCNet.py:268), summed in fp32, channels 0,1 of the one-group tensors
         h2, w2 = self.size[2]
-        s = self.head[2][:, 0, :, :, 0:2].float() + self.dc7[:, 0, :, :, 0:2].float()
-        self.flow_out.copy_(s.permute(0, 3, 1, 2))
+        torch.add(self.head[2][:, 0, :, :, 0:2].permute(0, 3, 1, 2), self.dc7[:, 0, :, :, 0:2].permute(0, 3, 1, 2),
+                  out=self.flow_out)
         return self.flow_out
