@@ -28,16 +28,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBlock = 320;          // waves 0..3: MFMA, wave 4: loader
 constexpr int kTileW = 32;
-constexpr int kNT = 2;               // rows per wave -> 8-row tiles
 constexpr unsigned kOOB = 0x80000000u;
 
 // R = ring depth (3 where the LDS allows it, 2 for the wide halos of dilation 8 / 16).  Dilation 16 stages the three
 // ky row-sets separately (3 x 8 rows instead of 40).
-template <int MT, int S, int D, int R>
+// NT = rows per MFMA wave: tile = 4*NT rows x 32 cols.  NT = 4 (16-row tiles, 2-slot ring) halves the filter bytes a
+// workgroup pulls from L2 per flop -- at ~1 PFLOP/s the 8-row tile moves 5.6 TB/s from L2, mostly filter slabs.
+template <int MT, int NT, int S, int D, int R>
 struct G16 {
     static_assert(R == 2 || R == 3, "ring depth");
     static constexpr int kRing = R;
-    static constexpr int kTileH = 4 * kNT;
+    static constexpr int kTileH = 4 * NT;
     static constexpr bool kRowSep = (D >= 16);
     static constexpr int kInH = kRowSep ? 3 * kTileH : (kTileH - 1) * S + 2 * D + 1;
     static constexpr int kInW = (kTileW - 1) * S + 2 * D + 1;
@@ -67,12 +68,13 @@ __device__ __forceinline__ void issue_f16(const _Float16 *xb, const _Float16 *wp
     for (int i = 0; i < G::kWInstr; ++i) pwc::dma_b128(rw, base + G::kWOffBytes + i * 1024, off[G::kInInstr + i]);
 }
 
-template <int MT, int S, int D, int R>
+template <int MT, int NT, int S, int D, int R>
 __global__ void __launch_bounds__(kBlock)
 conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp, const float *__restrict__ bias,
                    _Float16 *__restrict__ y, int Cg, int H, int W, int Cout, int CoutP, int Ho, int Wo,
                    int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int do_leaky) {
-    using G = G16<MT, S, D, R>;
+    using G = G16<MT, NT, S, D, R>;
+    constexpr int kNT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -255,9 +257,9 @@ struct Args16 {
     hipStream_t stream;
 };
 
-template <int MT, int S, int D, int R>
+template <int MT, int NT, int S, int D, int R>
 int launch16(const Args16 &a) {
-    using G = G16<MT, S, D, R>;
+    using G = G16<MT, NT, S, D, R>;
     if constexpr (!G::kValid) {
         PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: internal: MT=%d does not fit for stride %d dilation %d", MT, S, D);
     } else {
@@ -266,7 +268,7 @@ int launch16(const Args16 &a) {
         const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
         const int groups = (a.CoutP / 32 + MT - 1) / MT;
         if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
-        auto kern = conv3x3_f16_kernel<MT, S, D, R>;
+        auto kern = conv3x3_f16_kernel<MT, NT, S, D, R>;
         static pwc::LdsAttrOnce attr;
         if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
         // short-K layers (pyramid level 1: one or two chunks) only need as many ring slots as they have chunks: the
@@ -280,21 +282,32 @@ int launch16(const Args16 &a) {
     }
 }
 
-// widest cout tile that fits the LDS for this (stride, dilation), with a 3-slot ring if possible, else 2 slots;
-// PWC_CONV16F_MT / PWC_CONV16F_RING override (tuning)
+// Tile choice: widest cout tile that fits the LDS, 3-slot ring if possible, else 2 slots; 16-row tiles (NT = 4) for
+// stride-1 layers with >= 64 couts once the grid is large enough to keep every CU busy with them.
+// PWC_CONV16F_MT / PWC_CONV16F_RING / PWC_CONV16F_NT override (tuning).
 template <int S, int D>
 int dispatch16(const Args16 &a) {
     static const int forced_mt = [] { const char *e = getenv("PWC_CONV16F_MT"); return (e && *e) ? atoi(e) : 0; }();
     static const int forced_r = [] { const char *e = getenv("PWC_CONV16F_RING"); return (e && *e) ? atoi(e) : 0; }();
+    static const int forced_nt = [] { const char *e = getenv("PWC_CONV16F_NT"); return (e && *e) ? atoi(e) : 0; }();
     const int t32 = a.CoutP / 32;
     const int want = forced_mt > 0 ? min(forced_mt, t32) : min(t32, 4);
-#define PWC_TRY(MT_, R_)                                                                                   \
-    if (mt == MT_ && (forced_r == 0 || forced_r == R_)) {                                                  \
-        if constexpr (G16<MT_, S, D, R_>::kValid) return launch16<MT_, S, D, R_>(a);                       \
+    const int64_t tiles16 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 15) / 16);
+    // measured (batch 16, level 2): 96 couts 368 -> 336 us, 64 couts 312 -> 290 us; 128 couts (2 groups of 64) no gain
+    const bool tall = forced_nt ? forced_nt == 4 : (S == 1 && D <= 4 && (t32 == 2 || t32 == 3) && tiles16 >= 512);
+#define PWC_TRY(MT_, NT_, R_)                                                                                  \
+    if (mt == MT_ && (forced_r == 0 || forced_r == R_)) {                                                      \
+        if constexpr (G16<MT_, NT_, S, D, R_>::kValid) return launch16<MT_, NT_, S, D, R_>(a);                 \
+    }
+    if constexpr (S == 1 && D <= 4) {
+        if (tall) {
+            // (MT, NT) = (4, 4) would need 256 accumulator registers and spills with five waves per workgroup: use 2 x 4
+            for (int mt = (want == 4 ? 2 : want); mt >= 2; --mt) { PWC_TRY(3, 4, 2) PWC_TRY(2, 4, 2) }
+        }
     }
     for (int mt = want; mt >= 1; --mt) {
-        PWC_TRY(4, 3) PWC_TRY(3, 3) PWC_TRY(2, 3) PWC_TRY(1, 3)
-        PWC_TRY(4, 2) PWC_TRY(3, 2) PWC_TRY(2, 2) PWC_TRY(1, 2)
+        PWC_TRY(4, 2, 3) PWC_TRY(3, 2, 3) PWC_TRY(2, 2, 3) PWC_TRY(1, 2, 3)
+        PWC_TRY(4, 2, 2) PWC_TRY(3, 2, 2) PWC_TRY(2, 2, 2) PWC_TRY(1, 2, 2)
     }
 #undef PWC_TRY
     PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: no tile fits the LDS for stride %d dilation %d", S, D);

@@ -49,6 +49,8 @@ F16_CASES = [
     (2, 3, 16, 33, 70, 2, 1, True),             # image layer: 3 channels padded to one group
     (1, 96, 196, 14, 32, 2, 1, True),           # Cout not a multiple of 8
     (1, 64, 2, 9, 33, 1, 1, False),             # flow head, no activation
+    (16, 16, 64, 64, 256, 1, 1, True),          # >= 512 tiles of 16 rows and 64 couts: the 16-row tile (MT2, NT4, 2-slot ring)
+    (16, 8, 96, 60, 250, 1, 2, True),           # ... 96 couts (MT3, NT4), dilation 2, ragged edges
 ]
 
 
