@@ -69,12 +69,15 @@ def _norm_constants(device) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def normalize_pair(img1_u8: torch.Tensor, img2_u8: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[H,W,3] uint8 RGB -> [1,3,H,W] float, ToTensor + ImageNet normalisation (on the tensors' device)."""
+    """[H,W,3] (or batched [n,H,W,3]) uint8 RGB -> [1,3,H,W] ([n,3,H,W]) float, ToTensor + ImageNet normalisation
+    (on the tensors' device)."""
     mean, std = _norm_constants(img1_u8.device)
     outs = []
     for im in (img1_u8, img2_u8):
-        t = im[..., :3].permute(2, 0, 1).unsqueeze(0).to(torch.float32) / 255.0
-        outs.append((t - mean) / std)
+        t = im[..., :3].movedim(-1, -3)
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        outs.append((t.to(torch.float32) / 255.0 - mean) / std)
     return outs[0], outs[1]
 
 
@@ -257,9 +260,9 @@ class GraphedInfer:
     GPU-bound again.  ``__call__(pair_u8)`` takes the [2,H,W,3] uint8 device tensor PairStream(raw=True) yields and
     returns the [1,2,H,W] flow (a static buffer: consume or clone it before the next call)."""
 
-    def __init__(self, model, height: int, width: int, device: torch.device, reference_unpad: bool = True):
-        self.model, self.reference_unpad = model, reference_unpad
-        self.static_u8 = torch.zeros((2, height, width, 3), dtype=torch.uint8, device=device)
+    def __init__(self, model, height: int, width: int, device: torch.device, reference_unpad: bool = True, batch: int = 1):
+        self.model, self.reference_unpad, self.batch = model, reference_unpad, batch
+        self.static_u8 = torch.zeros((batch, 2, height, width, 3), dtype=torch.uint8, device=device)
         keep, model.use_graph = getattr(model, "use_graph", False), False      # no nested capture
         try:
             side = torch.cuda.Stream(device=device)
@@ -274,15 +277,63 @@ class GraphedInfer:
             model.use_graph = keep
 
     def _body(self) -> torch.Tensor:
-        i1, i2 = normalize_pair(self.static_u8[0], self.static_u8[1])
+        i1, i2 = normalize_pair(self.static_u8[:, 0], self.static_u8[:, 1])
         return model_infer(self.model, i1, i2, self.reference_unpad)
 
     def __call__(self, pair_u8: torch.Tensor) -> torch.Tensor:
-        if tuple(pair_u8.shape) != tuple(self.static_u8.shape) or pair_u8.dtype != torch.uint8:
-            raise ValueError("expected uint8 %s, got %s %s" % (tuple(self.static_u8.shape), pair_u8.dtype, tuple(pair_u8.shape)))
-        self.static_u8.copy_(pair_u8, non_blocking=True)
+        """pair_u8: [2,H,W,3] (one pair) or [n,2,H,W,3] with n <= batch; returns the first n flows [n,2,H,W]."""
+        if pair_u8.dim() == 4:
+            pair_u8 = pair_u8.unsqueeze(0)
+        n = pair_u8.shape[0]
+        if tuple(pair_u8.shape[1:]) != tuple(self.static_u8.shape[1:]) or pair_u8.dtype != torch.uint8 or not 1 <= n <= self.batch:
+            raise ValueError("expected uint8 [n<=%d,%s], got %s %s" % (self.batch, ",".join(map(str, self.static_u8.shape[1:])),
+                                                                      pair_u8.dtype, tuple(pair_u8.shape)))
+        self.static_u8[:n].copy_(pair_u8, non_blocking=True)
         self.graph.replay()
-        return self.out
+        return self.out[:n]
+
+
+class BatchStream:
+    """PairStream for batches: yields uint8 device tensors [n,2,H,W,3] (n = batch, fewer for the tail) from host uint8
+    pairs of one size, staged in two pinned buffers and uploaded on a side stream while the previous batch computes."""
+
+    def __init__(self, pairs: Iterable[Tuple[torch.Tensor, torch.Tensor]], device: torch.device, batch: int):
+        self.pairs, self.device, self.batch = iter(pairs), device, batch
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.slots, self.uploaded = [None, None], [None, None]
+
+    def _stage(self, slot: int):
+        n = 0
+        for a, b in self.pairs:
+            if self.slots[slot] is None:
+                self.slots[slot] = torch.empty((self.batch, 2) + tuple(a.shape[:2]) + (3,), dtype=torch.uint8).pin_memory()
+            elif n == 0 and self.uploaded[slot] is not None:
+                self.uploaded[slot].synchronize()
+            if tuple(a.shape[:2]) != tuple(self.slots[slot].shape[2:4]) or tuple(b.shape[:2]) != tuple(a.shape[:2]):
+                raise ValueError("BatchStream needs pairs of one size")
+            self.slots[slot][n, 0].copy_(a[..., :3])
+            self.slots[slot][n, 1].copy_(b[..., :3])
+            n += 1
+            if n == self.batch:
+                break
+        if n == 0:
+            return None
+        with torch.cuda.stream(self.copy_stream):
+            dev = self.slots[slot][:n].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.uploaded[slot] = ev
+        return dev, ev
+
+    def __iter__(self) -> Iterator[torch.Tensor]:
+        pending, slot = self._stage(0), 1
+        while pending is not None:
+            dev, ev = pending
+            pending = self._stage(slot)
+            slot ^= 1
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            dev.record_stream(torch.cuda.current_stream(self.device))
+            yield dev
 
 
 def evaluate_pairs(model, samples: Iterable[Tuple[torch.Tensor, torch.Tensor, np.ndarray, np.ndarray]],

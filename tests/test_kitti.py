@@ -150,3 +150,22 @@ def test_graphed_infer_equals_eager_pipeline(gpu_device):
         assert torch.equal(o, r)
     with pytest.raises(ValueError):
         pipe(torch.zeros((2, 64, 64, 3), dtype=torch.uint8, device=gpu_device))
+
+
+@pytest.mark.gpu
+def test_batched_graphed_infer_equals_eager(gpu_device):
+    """BatchStream + GraphedInfer(batch=2): batches of pairs per graph replay, ragged tail, same flows as pair-by-pair."""
+    from opticalflow_amd import PWCDCNet, kitti
+    from opticalflow_amd.weights import synthetic_state_dict
+    net = PWCDCNet().to(gpu_device).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=2, gain=0.85, bias_std=0.02))
+    g = torch.Generator().manual_seed(13)
+    samples = [(torch.randint(0, 256, (100, 150, 3), generator=g, dtype=torch.uint8),
+                torch.randint(0, 256, (100, 150, 3), generator=g, dtype=torch.uint8)) for _ in range(5)]
+    ref = torch.cat([kitti.model_infer(net, a, b).cpu() for a, b in kitti.PairStream(samples, gpu_device)], 0)
+    pipe = kitti.GraphedInfer(net, 100, 150, gpu_device, batch=2)
+    outs = [pipe(u8).cpu() for u8 in kitti.BatchStream(samples, gpu_device, 2)]
+    assert [o.shape[0] for o in outs] == [2, 2, 1]
+    got = torch.cat(outs, 0)
+    # the batch-2 plan may pick other conv tiles than the batch-1 plan (fp32 summation order): 1e-5 relative
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
