@@ -291,7 +291,12 @@ int dispatch16(const Args16 &a) {
     static const int forced_r = [] { const char *e = getenv("PWC_CONV16F_RING"); return (e && *e) ? atoi(e) : 0; }();
     static const int forced_nt = [] { const char *e = getenv("PWC_CONV16F_NT"); return (e && *e) ? atoi(e) : 0; }();
     const int t32 = a.CoutP / 32;
-    const int want = forced_mt > 0 ? min(forced_mt, t32) : min(t32, 4);
+    int want = forced_mt > 0 ? min(forced_mt, t32) : min(t32, 4);
+    // small grids (levels 6-4, batch-1 inference): narrower cout tiles = more workgroups; a workgroup's K loop is then
+    // bound by its DMA round trips instead of MT x as many MFMAs, and the tiny input is simply re-read per cout group
+    const int64_t tiles8 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 7) / 8);
+    if (forced_mt <= 0)
+        while (want > 1 && tiles8 * ((t32 + want - 1) / want) < 256) --want;
     const int64_t tiles16 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 15) / 16);
     // measured (batch 16, level 2): 96 couts 368 -> 336 us, 64 couts 312 -> 290 us; 128 couts (2 groups of 64) no gain
     const bool tall = forced_nt ? forced_nt == 4 : (S == 1 && D <= 4 && (t32 == 2 || t32 == 3) && tiles16 >= 512);
