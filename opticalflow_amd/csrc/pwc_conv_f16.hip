@@ -295,8 +295,9 @@ int dispatch16(const Args16 &a) {
     // small grids (levels 6-4, batch-1 inference): narrower cout tiles = more workgroups; a workgroup's K loop is then
     // bound by its DMA round trips instead of MT x as many MFMAs, and the tiny input is simply re-read per cout group
     const int64_t tiles8 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 7) / 8);
+    static const int kFillBlocks = [] { const char *e = getenv("PWC_CONV16F_FILL"); return (e && *e) ? atoi(e) : 256; }();
     if (forced_mt <= 0)
-        while (want > 1 && tiles8 * ((t32 + want - 1) / want) < 256) --want;
+        while (want > 1 && tiles8 * ((t32 + want - 1) / want) < kFillBlocks) --want;
     const int64_t tiles16 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 15) / 16);
     // measured (batch 16, level 2): 96 couts 368 -> 336 us, 64 couts 312 -> 290 us; 128 couts (2 groups of 64) no gain
     const bool tall = forced_nt ? forced_nt == 4 : (S == 1 && D <= 4 && (t32 == 2 || t32 == 3) && tiles16 >= 512);
