@@ -16,9 +16,10 @@ def short(n):
     m = re.search(r"conv3x3_mfma16_kernel<(\d+), (\d+)>", n)
     if m:
         return "mfma16<NT%s,CK%s>" % m.groups()
-    m = re.search(r"conv3x3_f16_kernel<(\d+), (\d+), (\d+), (\d+)>", n) or re.search(r"conv3x3_f16_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n)
+    m = (re.search(r"conv3x3_f16_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", n) or
+         re.search(r"conv3x3_f16_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n))
     if m:
-        return "f16conv<MT%s,S%s,D%s,R%s>" % m.groups()
+        return "f16conv<MT%s,NT%s,S%s,D%s,R%s>" % m.groups()
     for k in ("corr81_c8", "warp_c8", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
         if k in n:
             return k
