@@ -15,6 +15,7 @@ namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr unsigned kOOB = 0x80000000u;
 
@@ -184,9 +185,9 @@ image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, c
     const int b = (int)(i / oplane);
     const int pix = (int)(i - (int64_t)b * oplane);
     const int oy = pix / Wo, ox = pix - oy * Wo;
-    float acc[16];
+    f32x2 acc[8];                                    // (co, co+1) pairs: every fma below is a v_pk_fma_f32
 #pragma unroll
-    for (int co = 0; co < 16; ++co) acc[co] = sb[co];
+    for (int q = 0; q < 8; ++q) acc[q] = f32x2{sb[2 * q], sb[2 * q + 1]};
     const float *xb = x + (int64_t)b * bsx;
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
@@ -201,10 +202,8 @@ image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, c
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 wq = wr[q];
-                    acc[4 * q + 0] = fmaf(v, wq.x, acc[4 * q + 0]);
-                    acc[4 * q + 1] = fmaf(v, wq.y, acc[4 * q + 1]);
-                    acc[4 * q + 2] = fmaf(v, wq.z, acc[4 * q + 2]);
-                    acc[4 * q + 3] = fmaf(v, wq.w, acc[4 * q + 3]);
+                    acc[2 * q] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{wq.x, wq.y}, acc[2 * q]);
+                    acc[2 * q + 1] = __builtin_elementwise_fma(f32x2{v, v}, f32x2{wq.z, wq.w}, acc[2 * q + 1]);
                 }
             }
         }
@@ -213,7 +212,7 @@ image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, c
     for (int g = 0; g < 2; ++g) {
         h8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (_Float16)pwc::leaky(acc[g * 8 + j], slope);
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)pwc::leaky(acc[g * 4 + j / 2][j & 1], slope);
         *reinterpret_cast<h8 *>(yo + (int64_t)g * oplane * 8) = o;
     }
 }
