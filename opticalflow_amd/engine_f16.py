@@ -12,7 +12,9 @@
     (PWCNet.py:35-36), so head + upfeat are ONE convolution with 16 output channels (flow in group 0, the 8 upfeat
     phases in group 1) and ``deconvL`` is a second one on the flow group; the shuffles are strided copies.
 
-Inference (eval) only, PWCDCNet variant "dc".  Input/outputs stay float32 NCHW like the reference's interface.
+Inference (eval) only.  ``variant="old"`` (PWCDCNet_old, PWCNet.py:277-491) first brings that model's filters into
+PWCDCNet's concatenation order (engine.old_variant_perm), skips the ``*aa`` pyramid convs and uses the 0.999 mask
+threshold.  Input/outputs stay float32 NCHW like the reference's interface.
 """
 from __future__ import annotations
 
@@ -21,7 +23,8 @@ from typing import Dict
 import torch
 
 from . import ops_f16 as F16
-from .engine import CONTEXT, DENSE_OUT, LEAKY, PYRAMID_CH, PYRAMID_NAMES, WARP_SCALE, level_in_channels
+from .engine import (CONTEXT, DENSE_OUT, LEAKY, PYRAMID_CH, PYRAMID_NAMES, PYRAMID_NAMES_OLD, WARP_SCALE, level_in_channels,
+                     old_variant_perm)
 
 DENSE_G = (40, 24, 12, 4, 0)          # group offset of conv{L}_i's output (conv_0 .. conv_4) inside the arena
 BASE_G = 56                           # first group after the dense-block outputs
@@ -66,7 +69,12 @@ def _phys_index(level: int, nd: int = 81) -> torch.Tensor:
 
 class PwcPlanF16:
     def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device, md: int = 4,
-                 normalize_corr: bool = False, align_corners: bool = False):
+                 normalize_corr: bool = False, align_corners: bool = False, variant: str = "dc"):
+        if variant not in ("dc", "old"):
+            raise ValueError("variant must be 'dc' or 'old'")
+        self.variant = variant
+        self.pyramid_names = PYRAMID_NAMES if variant == "dc" else PYRAMID_NAMES_OLD
+        self.mask_threshold = 0.9999 if variant == "dc" else 0.999
         if H % 64 or W % 64 or H <= 0 or W <= 0:
             raise ValueError("PWCDCNet needs H and W to be positive multiples of 64 (got %dx%d)" % (H, W))
         if md != 4:
@@ -109,12 +117,19 @@ class PwcPlanF16:
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
 
         p = {k: v.detach().float() for k, v in params.items()}
+        if variant == "old":                       # same re-ordering as engine.PwcPlan: old concat order -> PWCDCNet's
+            for l in range(2, 7):
+                od = level_in_channels(l, self.nd)
+                keys = [("conv%d_%d.0.weight" % (l, k), k, 1) for k in range(1, 5)] + [("predict_flow%d.weight" % l, 5, 1)]
+                keys.append(("upfeat%d.weight" % l, 5, 0) if l > 2 else ("dc_conv1.0.weight", 5, 1))
+                for key, k, dim in keys:
+                    p[key] = p[key].index_select(dim, old_variant_perm(k, od).to(p[key].device)).contiguous()
         # conv1a (3 -> 16, stride 2) runs straight from the float32 image (ops_f16.image_conv_s2): keep its raw filters
         self.w1a = p["conv1a.0.weight"].contiguous()
         self.b1a = p["conv1a.0.bias"].contiguous()
-        for l, names in enumerate(PYRAMID_NAMES, start=1):
+        for l, names in enumerate(self.pyramid_names, start=1):
             for i, n in enumerate(names):
-                if l == 1 and i == 0:
+                if n is None or (l == 1 and i == 0):
                     continue
                 w = p[n + ".0.weight"]
                 put(n, _pad_cin(w, _groups(w.shape[1]) * 8), p[n + ".0.bias"])
@@ -173,14 +188,16 @@ class PwcPlanF16:
                 (B, 6, self.H, self.W), self.device, x.dtype, tuple(x.shape), x.device))
         prev = None
         for l in range(1, 7):
-            na, naa, nb = PYRAMID_NAMES[l - 1]
+            na, naa, nb = self.pyramid_names[l - 1]
             a, bb = self.pyr_a[l], self.pyr_b[l]
+            first = a if naa is not None else bb          # three convs a -> bb -> a; two for PWCDCNet_old: bb -> a
             if l == 1:
-                F16.image_conv_s2(x[:, :3], self.w1a, self.b1a, LEAKY, out=a[:B])
-                F16.image_conv_s2(x[:, 3:], self.w1a, self.b1a, LEAKY, out=a[B:])
+                F16.image_conv_s2(x[:, :3], self.w1a, self.b1a, LEAKY, out=first[:B])
+                F16.image_conv_s2(x[:, 3:], self.w1a, self.b1a, LEAKY, out=first[B:])
             else:
-                self._conv(na, prev, a, stride=2)
-            self._conv(naa, a, bb)
+                self._conv(na, prev, first, stride=2)
+            if naa is not None:
+                self._conv(naa, a, bb)
             self._conv(nb, bb, a)
             prev = a
         for l in (6, 5, 4, 3, 2):
@@ -194,7 +211,7 @@ class PwcPlanF16:
                 f0 = BASE_G + CORR_G
                 ar[:, f0:f0 + g].copy_(c1)
                 F16.warp_c8(c2, ar[:, f0 + g:f0 + g + 1], PYRAMID_CH[l], flo_channel=0, flow_scale=WARP_SCALE[l],
-                            align_corners=self.align_corners, out=self.warped[l])
+                            align_corners=self.align_corners, mask_threshold=self.mask_threshold, out=self.warped[l])
                 F16.correlation_c8(c1, self.warped[l], PYRAMID_CH[l], normalize=self.normalize_corr, leaky_slope=LEAKY,
                                    out=corr_slot)
             lo = BASE_G

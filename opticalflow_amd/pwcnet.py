@@ -162,11 +162,11 @@ class PWCDCNet(nn.Module):
                 if v.dtype != torch.float32:
                     raise NotImplementedError("parameters must be float32 (got %s for %s)" % (v.dtype, k))
             if self.precision == "fp16":
-                if self.variant != "dc" or self.conv_backend != "hip" or x.dtype != torch.float32:
-                    raise NotImplementedError("precision='fp16' is built for PWCDCNet, conv_backend='hip', float32 input")
+                if self.conv_backend != "hip" or x.dtype != torch.float32:
+                    raise NotImplementedError("precision='fp16' is built for conv_backend='hip' and float32 input")
                 from .engine_f16 import PwcPlanF16
                 plan = PwcPlanF16(params, x.shape[0], x.shape[2], x.shape[3], x.device, self.md,
-                                  self.normalize_corr, self.align_corners)
+                                  self.normalize_corr, self.align_corners, self.variant)
             else:
                 plan = PwcPlan(params, x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype, self.md,
                                self.normalize_corr, self.align_corners, self.conv_backend, self.variant)

@@ -190,3 +190,34 @@ def test_image_conv_s2_vs_torch(dev):
         got = F16.from_c8(F16.image_conv_s2(xd[:, half], w.to(dev), b.to(dev)), 16).cpu().double()
         assert got.shape == ref.shape == (2, 16, 19, 35)
         assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_forward_fp16_old_variant(dev):
+    """PWCDCNet_old through the half-precision plan.  Levels 6..3 must agree with the fp32 plan of the same model to
+    1e-2 relative.  At level 2 of the 64x64 golden input (a 16x16 map) the warp's hard validity threshold (0.999 for this
+    variant) lets ONE pixel flip when the flow is rounded to half (a sample point ~1e-3 px from the border), and the
+    dilated context network spreads that over the whole tiny map: the final flow is therefore held to 5e-2 x mean |flow|
+    against the reference's output (golden g6) -- observed 4e-2 on 's'; the dc variant (threshold 0.9999) meets 1e-2."""
+    from conftest import load_golden
+    from opticalflow_amd import pwcnet
+    from opticalflow_amd.weights import synthetic_state_dict
+    from oracle import pwc_oracle as O
+    g = load_golden("g6_old.npz")
+    sd = synthetic_state_dict(pwcnet.PWCDCNet_old().manifest(), seed=int(g["wseed"]), gain=float(g["gain"]), bias_std=float(g["bias_std"]))
+    net16 = pwcnet.PWCDCNet_old(precision="fp16").to(dev).eval()
+    net32 = pwcnet.PWCDCNet_old().to(dev).eval()
+    net16.load_state_dict(sd)
+    net32.load_state_dict(sd)
+    for tag in ("s", "m"):
+        x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag]).to(dev)
+        f16, f32 = net16(x).cpu(), net32(x).cpu()
+        p16, p32 = net16._plan_for(x), net32._plan_for(x)
+        for l in (6, 5, 4, 3):
+            a = p32.flow[l]
+            b = p16.head[l][:, 0, :, :, 0:2].permute(0, 3, 1, 2).float()
+            assert (a - b).abs().max().item() <= 1e-2 * max(a.abs().max().item(), 1e-3), (tag, l)
+        ref = torch.from_numpy(g["flow2_" + tag])
+        assert O.epe(f32, ref) < 1e-3
+        epe, scale = O.epe(f16, ref), ref.abs().mean().item()
+        print("fp16 old [%s]: EPE %.3e, mean|flow| %.3f" % (tag, epe, scale))
+        assert epe <= 5e-2 * scale, (tag, epe, scale)
