@@ -155,7 +155,8 @@ def probes_fp16(result, plan, B, H, W, h2, w2, stream):
     result["roofline"] = {"kernel": "conv3x3_f16_kernel<4, 1, 1, 3> = <MT,stride,dilation,ring> (dc_conv1 565->128 @%dx%d, B=%d, "
                                     "v_mfma_f32_32x32x16_f16)" % (w2, h2, B),
                           "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+                          "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
+                          "traffic": pmc_traffic("conv3x3_f16_dc_conv1_b16", B == 16 and (H, W) == (448, 1024)),
                           "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
     ar = plan.arena[2]
     f0 = BASE_G + CORR_G
