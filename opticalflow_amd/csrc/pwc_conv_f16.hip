@@ -298,6 +298,12 @@ int dispatch16(const Args16 &a) {
     static const int kFillBlocks = [] { const char *e = getenv("PWC_CONV16F_FILL"); return (e && *e) ? atoi(e) : 256; }();
     if (forced_mt <= 0)
         while (want > 1 && tiles8 * ((t32 + want - 1) / want) < kFillBlocks) --want;
+    // short K (<= 12 chunks = 192 input channels: conv2_0, dc_conv2/3, the pyramid): a workgroup's prologue and epilogue
+    // are a large share of its life, so prefer 64-cout tiles with a 2-slot ring -- two workgroups then share a CU and
+    // cover each other (conv2_0 177 -> 142 us, dc_conv2 190 -> 150 us at batch 16; long-K layers lose with it)
+    static const int short_k = [] { const char *e = getenv("PWC_CONV16F_SHORTK"); return (e && *e) ? atoi(e) : 12; }();
+    const bool two_per_cu = forced_mt <= 0 && forced_r == 0 && (a.Cg + 1) / 2 <= short_k && t32 >= 2 && tiles8 >= 1024;
+    if (two_per_cu && want > 2) want = 2;
     const int64_t tiles16 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 15) / 16);
     // measured (batch 16, level 2): 96 couts 368 -> 336 us, 64 couts 312 -> 290 us; 128 couts (2 groups of 64) no gain
     const bool tall = forced_nt ? forced_nt == 4 : (S == 1 && D <= 4 && (t32 == 2 || t32 == 3) && tiles16 >= 512);
@@ -310,6 +316,9 @@ int dispatch16(const Args16 &a) {
             // (MT, NT) = (4, 4) would need 256 accumulator registers and spills with five waves per workgroup: use 2 x 4
             for (int mt = (want == 4 ? 2 : want); mt >= 2; --mt) { PWC_TRY(3, 4, 2) PWC_TRY(2, 4, 2) }
         }
+    }
+    if (two_per_cu) {
+        for (int mt = want; mt >= 1; --mt) { PWC_TRY(2, 2, 2) PWC_TRY(1, 2, 2) }
     }
     for (int mt = want; mt >= 1; --mt) {
         PWC_TRY(4, 2, 3) PWC_TRY(3, 2, 3) PWC_TRY(2, 2, 3) PWC_TRY(1, 2, 3)
