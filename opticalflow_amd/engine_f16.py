@@ -88,8 +88,8 @@ class PwcPlanF16:
         for l in range(1, 7):
             h, w = self.size[l]
             g = _groups(PYRAMID_CH[l])
-            self.pyr_a[l] = torch.zeros((2 * B, g, h, w, 8), **hk)
-            self.pyr_b[l] = torch.zeros((2 * B, g, h, w, 8), **hk)
+            self.pyr_a[l] = torch.zeros((self._slots(B), g, h, w, 8), **hk)
+            self.pyr_b[l] = torch.zeros((self._slots(B), g, h, w, 8), **hk)
         self.arena, self.warped, self.head, self.upflow = {}, {}, {}, {}
         for l in range(2, 7):
             h, w = self.size[l]
@@ -168,6 +168,10 @@ class PwcPlanF16:
             put("dc_conv%d" % i, _pad_cin(w, _groups(w.shape[1]) * 8), p["dc_conv%d.0.bias" % i])
         put("dc_conv7", _pad_cin(p["dc_conv7.weight"], 32), p["dc_conv7.bias"])
 
+    @staticmethod
+    def _slots(B: int) -> int:
+        return 2 * B
+
     # ---- primitives -------------------------------------------------------------------------------------------------
     def _conv(self, name, x, out, stride=1, dilation=1, act=True):
         F16.conv3x3_f16(x, self.w[name], self.b[name], self.cin[name], self.cout[name], stride=stride, dilation=dilation,
@@ -186,24 +190,36 @@ class PwcPlanF16:
         if tuple(x.shape) != (B, 6, self.H, self.W) or x.dtype != torch.float32 or x.device != self.device:
             raise ValueError("plan built for float32 %s on %s, got %s %s on %s" % (
                 (B, 6, self.H, self.W), self.device, x.dtype, tuple(x.shape), x.device))
+        self._pyramid([(x[:, :3], 0, B), (x[:, 3:], B, 2 * B)], 0, 2 * B)
+        return self._decode()
+
+    def _pair_views(self, l: int):
+        """first / second image's level features as views of the pyramid buffer"""
+        return self.pyr_a[l][:self.B], self.pyr_a[l][self.B:]
+
+    def _pyramid(self, images, lo: int, hi: int) -> None:
+        """conv1a..conv6b over the batch slots [lo,hi); `images` lists (rgb float32 [n,3,H,W], slot_lo, slot_hi)."""
         prev = None
         for l in range(1, 7):
             na, naa, nb = self.pyramid_names[l - 1]
-            a, bb = self.pyr_a[l], self.pyr_b[l]
-            first = a if naa is not None else bb          # three convs a -> bb -> a; two for PWCDCNet_old: bb -> a
+            a, bb = self.pyr_a[l][lo:hi], self.pyr_b[l][lo:hi]
+            first = self.pyr_a[l] if naa is not None else self.pyr_b[l]   # three convs a -> bb -> a; PWCDCNet_old: bb -> a
             if l == 1:
-                F16.image_conv_s2(x[:, :3], self.w1a, self.b1a, LEAKY, out=first[:B])
-                F16.image_conv_s2(x[:, 3:], self.w1a, self.b1a, LEAKY, out=first[B:])
+                for img, s0, s1 in images:
+                    F16.image_conv_s2(img, self.w1a, self.b1a, LEAKY, out=first[s0:s1])
             else:
-                self._conv(na, prev, first, stride=2)
+                self._conv(na, prev, first[lo:hi], stride=2)
             if naa is not None:
                 self._conv(naa, a, bb)
             self._conv(nb, bb, a)
             prev = a
+
+    def _decode(self) -> torch.Tensor:
+        B = self.B
         for l in (6, 5, 4, 3, 2):
             ar = self.arena[l]
             g = _groups(PYRAMID_CH[l])
-            c1, c2 = self.pyr_a[l][:B], self.pyr_a[l][B:]
+            c1, c2 = self._pair_views(l)
             corr_slot = ar[:, BASE_G:BASE_G + CORR_G]
             if l == 6:
                 F16.correlation_c8(c1, c2, PYRAMID_CH[6], normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
@@ -235,3 +251,48 @@ class PwcPlanF16:
         torch.add(self.head[2][:, 0, :, :, 0:2].permute(0, 3, 1, 2), self.dc7[:, 0, :, :, 0:2].permute(0, 3, 1, 2),
                   out=self.flow_out)
         return self.flow_out
+
+
+class PwcVideoPlanF16(PwcPlanF16):
+    """Half-precision plan for consecutive frame pairs of one video (pwc_extract_flow_video.py:262-305): B+1 batch
+    slots per pyramid buffer, slot 0 carries the last frame of the previous step, the pair views overlap ([0:B] / [1:B+1]),
+    one pyramid pass per frame -- the fp16 twin of engine.PwcVideoPlan."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.primed = False
+
+    @staticmethod
+    def _slots(B: int) -> int:
+        return B + 1
+
+    def _pair_views(self, l: int):
+        return self.pyr_a[l][:self.B], self.pyr_a[l][1:]
+
+    def _check(self, frames: torch.Tensor, n: int) -> torch.Tensor:
+        if tuple(frames.shape) != (n, 3, self.H, self.W) or frames.dtype != torch.float32 or frames.device != self.device:
+            raise ValueError("expected float32 frames %s on %s, got %s %s on %s" % (
+                (n, 3, self.H, self.W), self.device, frames.dtype, tuple(frames.shape), frames.device))
+        return frames.contiguous()
+
+    def _carry(self) -> None:
+        for l in range(2, 7):
+            self.pyr_a[l][0].copy_(self.pyr_a[l][self.B])
+
+    def prime(self, frame: torch.Tensor) -> None:
+        f = self._check(frame, 1)
+        self._pyramid([(f, self.B, self.B + 1)], self.B, self.B + 1)
+        self._carry()
+        self.primed = True
+
+    def push(self, frames: torch.Tensor) -> torch.Tensor:
+        if not self.primed:
+            raise RuntimeError("PwcVideoPlanF16.push before prime(first_frame)")
+        f = self._check(frames, self.B)
+        self._pyramid([(f, 1, self.B + 1)], 1, self.B + 1)
+        out = self._decode()
+        self._carry()
+        return out
+
+    def run(self, x):
+        raise RuntimeError("PwcVideoPlanF16 is driven by prime()/push(), not run()")

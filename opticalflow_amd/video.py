@@ -47,9 +47,14 @@ class FlowStream:
             raise PwcHipError("FlowStream needs the model on the ROCm device (parameters are on %s)" % p0.device)
         self.device = p0.device
         self.batch, self.height, self.width = batch, height, width
-        self.plan = PwcVideoPlan(params, batch, height, width, self.device, torch.float32, net.md,
-                                 net.normalize_corr, net.align_corners, net.conv_backend,
-                                 getattr(net, "variant", "dc"))
+        if getattr(net, "precision", "fp32") == "fp16":
+            from .engine_f16 import PwcVideoPlanF16
+            self.plan = PwcVideoPlanF16(params, batch, height, width, self.device, net.md, net.normalize_corr,
+                                        net.align_corners, getattr(net, "variant", "dc"))
+        else:
+            self.plan = PwcVideoPlan(params, batch, height, width, self.device, torch.float32, net.md,
+                                     net.normalize_corr, net.align_corners, net.conv_backend,
+                                     getattr(net, "variant", "dc"))
         self.use_graph = use_graph
         self._graph = None
         self._static = torch.empty((batch, 3, height, width), device=self.device, dtype=torch.float32)

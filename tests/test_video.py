@@ -51,6 +51,26 @@ def test_flow_stream_matches_pairwise_forward(gpu_device, batch, use_graph):
 
 
 @pytest.mark.gpu
+def test_flow_stream_fp16(gpu_device):
+    """the half-precision stream plan reuses the pyramid too and agrees with the fp16 per-pair forward."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.video import FlowStream
+    from opticalflow_amd.weights import synthetic_state_dict
+    dev = gpu_device
+    net = PWCDCNet(precision="fp16").to(dev).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=3, gain=0.85, bias_std=0.02))
+    H, W, batch = 128, 192, 2
+    frames = seeded_rand((1 + 2 * batch, 3, H, W), 78, 0, 1).to(dev)
+    stream = FlowStream(net, batch, H, W, use_graph=True)
+    stream.prime(frames[0])
+    got = torch.cat([stream.push(frames[1 + k * batch:1 + (k + 1) * batch]).clone() for k in range(2)], 0)
+    ref = net(torch.cat([frames[:-1], frames[1:]], 1))
+    assert got.shape == ref.shape and ref.abs().max().item() > 1e-2
+    # same kernels on the same half-precision features; only the pyramid's batch size (tile choice) may differ
+    assert (got - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
 def test_flow_video_generator_matches_reference_loop(gpu_device):
     """flow_video() == the reference loop's process_frame_pair on each pair, incl. its pad/unpad quirk."""
     from opticalflow_amd import PWCDCNet

@@ -1,5 +1,5 @@
 """Frames/s of the pyramid-reusing FlowStream vs. the per-pair forward (video loop, pwc_extract_flow_video.py:262-305).
-usage: python tools/bench_video.py [H W] [batches...]"""
+usage: [PWC_PRECISION=fp16] python tools/bench_video.py [H W] [batches...]"""
 import os
 import sys
 import time
@@ -27,7 +27,7 @@ def main():
     H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (448, 1024)
     batches = [int(a) for a in sys.argv[3:]] or [1, 4, 16]
     dev = torch.device("cuda:0")
-    net = PWCDCNet(use_graph=True).to(dev).eval()
+    net = PWCDCNet(use_graph=True, precision=os.environ.get("PWC_PRECISION", "fp32")).to(dev).eval()
     net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
     for B in batches:
         frames = torch.rand((B + 1, 3, H, W), device=dev)
