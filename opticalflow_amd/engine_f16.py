@@ -193,6 +193,10 @@ class PwcPlanF16:
         self._pyramid([(x[:, :3], 0, B), (x[:, 3:], B, 2 * B)], 0, 2 * B)
         return self._decode()
 
+    def flows(self):
+        """(flow2, flow3, flow4, flow5, flow6) of the last run as float32 NCHW -- the training-mode return (PWCNet.py:270-271)."""
+        return (self.flow_out,) + tuple(self.head[l][:, 0, :, :, 0:2].permute(0, 3, 1, 2).float() for l in (3, 4, 5, 6))
+
     def _pair_views(self, l: int):
         """first / second image's level features as views of the pyramid buffer"""
         return self.pyr_a[l][:self.B], self.pyr_a[l][self.B:]

@@ -53,7 +53,7 @@ class PWCDCNet(nn.Module):
         if precision not in ("fp32", "fp16"):
             raise ValueError("precision must be 'fp32' or 'fp16'")
         # 'fp16' (BASELINE configs 3-4): float32 parameters and float32 input/output as in the reference's interface,
-        # half-precision activations and filters inside, fp32 accumulation (engine_f16.PwcPlanF16); eval mode only
+        # half-precision activations and filters inside, fp32 accumulation (engine_f16.PwcPlanF16)
         self.precision = precision
         self.md = md
         self.normalize_corr = normalize_corr
@@ -115,9 +115,6 @@ class PWCDCNet(nn.Module):
         if not x.is_cuda:
             raise PwcHipError("PWCDCNet.forward needs a tensor on the ROCm device (got %s): the HIP path has no "
                               "CPU fallback" % x.device)
-        if self.training and self.precision == "fp16":
-            raise NotImplementedError("precision='fp16' is inference only (call .eval()): the 5-tuple of training mode "
-                                      "is produced by the fp32 plan")
         plan = self._plan_for(x)
         key = self._key(x)
         if self.use_graph and not self.training:

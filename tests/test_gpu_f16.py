@@ -171,9 +171,12 @@ def test_forward_fp16_vs_reference_golden(dev):
     eager = net(x)
     net.use_graph = True
     assert torch.equal(net(x), eager) and torch.equal(net(x), eager)
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(x)
+    net.train()                                     # training mode returns the 5-tuple (PWCNet.py:270-271), as float32
+    outs = net(x)
+    assert len(outs) == 5 and all(o.dtype == torch.float32 for o in outs)
+    for lvl, o in zip((2, 3, 4, 5, 6), outs):
+        ref_l = torch.from_numpy(g["train_flow%d_m" % lvl])
+        assert o.shape == ref_l.shape and O.epe(o.cpu(), ref_l) <= 1e-2 * max(ref_l.abs().mean().item(), 1e-2), lvl
     with pytest.raises(ValueError):
         PWCDCNet(precision="bf16")
 
