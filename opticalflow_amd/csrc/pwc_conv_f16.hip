@@ -302,7 +302,7 @@ int dispatch16(const Args16 &a) {
     // are a large share of its life, so prefer 64-cout tiles with a 2-slot ring -- two workgroups then share a CU and
     // cover each other (conv2_0 177 -> 142 us, dc_conv2 190 -> 150 us at batch 16; long-K layers lose with it)
     static const int short_k = [] { const char *e = getenv("PWC_CONV16F_SHORTK"); return (e && *e) ? atoi(e) : 12; }();
-    const bool two_per_cu = forced_mt <= 0 && forced_r == 0 && (a.Cg + 1) / 2 <= short_k && t32 >= 2 && tiles8 >= 1024;
+    const bool two_per_cu = forced_mt <= 0 && forced_r == 0 && (a.Cg + 1) / 2 <= short_k && t32 >= 2 && tiles8 >= 1024 && D <= 4;   // wide halos (dilation 8, 16): re-reading the input per 64-cout group costs more than it gains (dc_conv4 151 -> 252 us)
     if (two_per_cu && want > 2) want = 2;
     const int64_t tiles16 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 15) / 16);
     // measured (batch 16, level 2): 96 couts 368 -> 336 us, 64 couts 312 -> 290 us; 128 couts (2 groups of 64) no gain
