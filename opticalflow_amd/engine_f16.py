@@ -12,7 +12,7 @@
     (PWCNet.py:35-36), so head + upfeat are ONE convolution with 16 output channels (flow in group 0, the 8 upfeat
     phases in group 1) and ``deconvL`` is a second one on the flow group; the shuffles are strided copies.
 
-Inference (eval) only.  ``variant="old"`` (PWCDCNet_old, PWCNet.py:277-491) first brings that model's filters into
+No autograd (like the fp32 plan); training mode returns the 5-tuple via ``flows()``.  ``variant="old"`` (PWCDCNet_old, PWCNet.py:277-491) first brings that model's filters into
 PWCDCNet's concatenation order (engine.old_variant_perm), skips the ``*aa`` pyramid convs and uses the 0.999 mask
 threshold.  Input/outputs stay float32 NCHW like the reference's interface.
 """

@@ -1,8 +1,8 @@
-"""fp16 building blocks (first piece of the half-precision path, BASELINE configs 3-4): channel-blocked "c8"
-activations ``[B, ceil(C/8), H, W, 8]`` (torch.float16) and the MFMA 3x3 convolution over them.
+"""Half-precision building blocks (BASELINE configs 3-4): channel-blocked "c8" activations
+``[B, ceil(C/8), H, W, 8]`` (torch.float16) and the kernels over them -- MFMA 3x3 convolution, first pyramid layer from
+the float32 image, PWC-Net's cost volume, the warp, layout conversions.  engine_f16.PwcPlanF16 assembles the network.
 
 Device tensors only; every function launches kernels of libpwc_hip.so on the current stream (no CPU path).
-The full fp16 network is not assembled yet: correlation / warp / heads in c8 layout are the next round's work.
 """
 from __future__ import annotations
 
