@@ -311,6 +311,29 @@ def main():
         with torch.no_grad():
             ref = O.pwc_forward(sd_cpu, xs)
         result["epe_vs_cpu_oracle_64x128"] = float("%.3e" % O.epe(net(xs.to(dev)).cpu(), ref))
+        if world == 1 and fp32 and args.conv_backend == "hip" and not args.no_graph:
+            # side measurement, not the metric: the same workload through the half-precision plan (BASELINE configs[3]
+            # per-GPU shard), timed the same way after the fp32 region; `python bench.py --precision fp16` is the full line
+            log("side measurement: same workload, precision=fp16")
+            net16 = PWCDCNet(use_graph=True, precision="fp16").to(dev).eval()
+            net16.load_state_dict(net.state_dict())
+            x16 = net16.graph_input(B, H, W, dev)
+            x16.copy_(x)
+            for _ in range(3):
+                net16(x16)
+            torch.cuda.synchronize()
+            t16 = time.perf_counter()
+            for _ in range(args.steps):
+                out16 = net16(x16)
+            torch.cuda.synchronize()
+            dt16 = time.perf_counter() - t16
+            f32out = net(x)
+            result["fp16_same_workload"] = {
+                "value": round(B * args.steps / dt16, 3), "unit": "image-pairs/s", "ms_per_step": round(1e3 * dt16 / args.steps, 4),
+                "dtype": "f16 activations/filters, f32 accumulation",
+                "epe_vs_fp32_plan": float("%.3e" % O.epe(out16.cpu(), f32out.cpu())),
+                "mean_abs_flow": float("%.3e" % f32out.abs().mean().item())}
+            del net16
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
             torch.set_num_threads(cores)
