@@ -114,6 +114,36 @@ corr81_c8_kernel(const _Float16 *__restrict__ in1, const _Float16 *__restrict__ 
     }
 }
 
+// Small maps (pyramid levels 6-4): the tiled kernel above has only B*ceil(H/8)*ceil(W/32) workgroups, each walking all
+// channel groups serially (level 6: 16 workgroups x 7 DMA round trips = 52 us).  Here one thread owns ONE output value
+// (pixel, displacement) and streams the channel groups straight from L2: 88 threads per pixel, no LDS.
+__global__ void __launch_bounds__(256)
+corr81_c8_direct_kernel(const _Float16 *__restrict__ in1, const _Float16 *__restrict__ in2, _Float16 *__restrict__ out,
+                        int Cg, int H, int W, int64_t total, int64_t bs1, int64_t bs2, int64_t bso,
+                        float scale, float slope, int do_leaky) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int d = (int)(i % 88);                       // output channel 0..87 (81..87 = zero padding)
+    int64_t t = i / 88;
+    const int plane = H * W;
+    const int pix = (int)(t % plane);
+    const int b = (int)(t / plane);
+    const int y = pix / W, x = pix - y * W;
+    float acc = 0.f;
+    if (d < 81) {
+        const int y2 = y + d / 9 - 4, x2 = x + d % 9 - 4;
+        if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
+            const _Float16 *p1 = in1 + (int64_t)b * bs1 + (int64_t)pix * 8;
+            const _Float16 *p2 = in2 + (int64_t)b * bs2 + ((int64_t)y2 * W + x2) * 8;
+            for (int g = 0; g < Cg; ++g, p1 += (int64_t)plane * 8, p2 += (int64_t)plane * 8)
+                acc = dot8(*reinterpret_cast<const h8 *>(p1), *reinterpret_cast<const h8 *>(p2), acc);
+        }
+        acc *= scale;
+        if (do_leaky) acc = pwc::leaky(acc, slope);
+    }
+    out[(int64_t)b * bso + ((int64_t)(d >> 3) * plane + pix) * 8 + (d & 7)] = (_Float16)acc;
+}
+
 // ---- warp ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo, _Float16 *__restrict__ out,
@@ -249,6 +279,14 @@ extern "C" int pwc_corr81_c8_f16(const void *in1, const void *in2, void *out, in
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr81_c8_f16: grid too large");
     const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
+    if (nblk < 256) {                                     // fewer tiles than CUs: one thread per output value instead
+        const int64_t total = (int64_t)B * plane * 88;
+        hipLaunchKernelGGL(corr81_c8_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const _Float16 *>(in1), static_cast<const _Float16 *>(in2), static_cast<_Float16 *>(out),
+                           cg, H, W, total, in1_bstride, in2_bstride, out_bstride, scale, leaky_slope,
+                           (flags & PWC_ACT_LEAKY) ? 1 : 0);
+        return pwc::check_launch("corr81_c8_direct_kernel");
+    }
     hipLaunchKernelGGL(corr81_c8_kernel, dim3((unsigned)nblk), dim3(kCThreads), 0, static_cast<hipStream_t>(stream),
                        static_cast<const _Float16 *>(in1), static_cast<const _Float16 *>(in2), static_cast<_Float16 *>(out),
                        cg, H, W, tiles_x, tiles_y, in1_bstride, in2_bstride, out_bstride, scale, leaky_slope,

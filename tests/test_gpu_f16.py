@@ -109,7 +109,9 @@ def _to_c8_cpu(x: torch.Tensor) -> torch.Tensor:
     return pad.view(B, cg, 8, H, W).permute(0, 1, 3, 4, 2).contiguous().half()
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 24, 64), (1, 196, 7, 16), (1, 96, 13, 37), (2, 13, 9, 5)])
+# small maps take the one-thread-per-output kernel, >= 256 tiles the LDS-tiled one (last two cases, one with ragged edges)
+@pytest.mark.parametrize("shape", [(2, 32, 24, 64), (1, 196, 7, 16), (1, 96, 13, 37), (2, 13, 9, 5), (4, 32, 112, 256),
+                                   (5, 40, 100, 250)])
 def test_correlation_c8_vs_oracle(dev, shape):
     """fp16 cost volume vs the CPU oracle on the same fp16-rounded inputs (fp32 accumulation in the kernel, one
     rounding of the result to half: 1e-3 relative)."""
