@@ -81,6 +81,11 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     int bid = blockIdx.x;
+#ifndef PWC_F16_NO_XCD_MAP
+    // workgroups i, i+8, i+16, ... run on the same XCD: deal the tiles so that each XCD owns a contiguous run of them and
+    // the halo rows / columns re-read by neighbouring tiles hit in that XCD's L2 (speed only; any mapping is correct)
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+#endif
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
