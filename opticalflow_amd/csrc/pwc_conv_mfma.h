@@ -125,6 +125,10 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     const int kh = lane >> 5;
 
     int bid = blockIdx.x;
+#ifndef PWC_CONV_NO_XCD_MAP
+    // workgroups i, i+8, ... share an XCD: give each XCD a contiguous run of tiles so that halo re-reads hit its L2
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+#endif
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
@@ -274,6 +278,10 @@ conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp,
     const int kg = lane >> 4;           // A, B: channel inside the group of 4 / D: cout rows 4*kg .. 4*kg+3
 
     int bid = blockIdx.x;
+#ifndef PWC_CONV_NO_XCD_MAP
+    // workgroups i, i+8, ... share an XCD: give each XCD a contiguous run of tiles so that halo re-reads hit its L2
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+#endif
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
