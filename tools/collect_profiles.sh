@@ -21,14 +21,14 @@ python3 "$ROOT/tools/bench_video.py" 448 1024 1 16 > "$OUT/bench_video.txt" 2>&1
 say "kernel trace + stats, batch 16"
 rocprofv3 --kernel-trace --stats -d "$OUT/prof_b16" -o b16 --output-format csv -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/prof_b16.log" 2>&1
 f=$(find "$OUT/prof_b16" -name "*kernel_trace.csv" | head -1)
-python3 "$ROOT/tools/timeline.py" "$f" --full > "$OUT/forward_timeline_b16.txt"
+python3 "$ROOT/tools/timeline.py" "$f" --full --fp32 > "$OUT/forward_timeline_b16.txt"
 cp "$(find "$OUT/prof_b16" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_bench_b16.csv"
 rm -rf "$OUT/prof_b16"
 
 say "kernel trace, batch 1"
 rocprofv3 --kernel-trace -d "$OUT/prof_b1" -o b1 --output-format csv -- python3 "$ROOT/bench.py" --batch 1 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof_b1.log" 2>&1
 f=$(find "$OUT/prof_b1" -name "*kernel_trace.csv" | head -1)
-python3 "$ROOT/tools/timeline.py" "$f" --full --min-grid=50000 > "$OUT/forward_timeline_b1.txt"
+python3 "$ROOT/tools/timeline.py" "$f" --full --fp32 --min-grid=50000 > "$OUT/forward_timeline_b1.txt"
 rm -rf "$OUT/prof_b1"
 
 say "kernel stats of the dominant kernel alone (dc_conv1) and of the level-2 correlation"

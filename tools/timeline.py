@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per-launch timeline of ONE forward of bench.py.
 
-usage: tools/timeline.py <kernel_trace.csv> [--full] [--min-grid=N]
+usage: tools/timeline.py <kernel_trace.csv> [--full] [--min-grid=N] [--fp32]
+--fp32: the trace also holds fp16 forwards (bench.py's fp16_same_workload leg); pick the fp32 plan's forward.
 A forward starts at the two back-to-back stride-2 launches of conv1a on the two images.
 """
 import csv
@@ -37,19 +38,27 @@ def main():
             min_grid = int(a.split("=")[1])
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
-    if any(n == "image_conv_s2" for n in names):   # fp16 plan: a forward starts with conv1a on the two images
+    if "--fp32" not in sys.argv and any(n == "image_conv_s2" for n in names):   # fp16 plan: a forward starts with conv1a on the two images
         starts = [i for i in range(len(rows) - 1) if names[i] == "image_conv_s2" and names[i + 1] == "image_conv_s2"
                   and int(rows[i]["Grid_Size_X"]) > min_grid]
         rows_ok = True
     else:
         rows_ok = False
     starts = starts if rows_ok else [i for i in range(len(rows) - 1)
-              if ("S2,D1" in names[i]) and names[i + 1] == names[i]
+              if names[i].startswith("mfma<") and ("S2,D1" in names[i]) and names[i + 1] == names[i]
               and rows[i]["Grid_Size_X"] == rows[i + 1]["Grid_Size_X"] and int(rows[i]["Grid_Size_X"]) > min_grid]
     if len(starts) < 3:
         print("no forward found")
         return
     s, e = starts[-2], starts[-1]
+    if "--fp32" in sys.argv:   # the last back-to-back pair of fp32 forwards with nothing else between them
+        def span(i):
+            return int(rows[starts[i + 1]]["Start_Timestamp"]) - int(rows[starts[i]]["Start_Timestamp"])
+        pure = [i for i in range(len(starts) - 1)
+                if not any(n.startswith("f16conv") or n == "image_conv_s2" for n in names[starts[i]:starts[i + 1]])]
+        best = min(span(i) for i in pure)
+        i = [i for i in pure if span(i) <= 1.2 * best][-1]
+        s, e = starts[i], starts[i + 1]
     t0 = int(rows[s]["Start_Timestamp"])
     agg = {}
     tot = 0.0
