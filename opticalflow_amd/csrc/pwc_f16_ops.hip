@@ -200,7 +200,13 @@ warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo,
 // conv1a (3 -> 16, stride 2, pad 1) + LeakyReLU straight from the float32 NCHW image to c8 halves: with K = 27 the MFMA
 // kernel is pure per-workgroup overhead (324 us at batch 16 + 106 us of layout conversion); here one thread computes
 // the 16 channels of one output pixel from its 3x3x3 window (432 fma), weights broadcast from LDS.
-__global__ void __launch_bounds__(256)
+// waves_per_eu: left alone, the compiler hoists all 108 weight reads above the fma chain (500 registers, ONE wave per
+// SIMD, every latency exposed: 127 us per launch at batch 16); capped at PWC_IMAGE_CONV_WAVES waves' worth of registers
+// the reads interleave with the fmas and the other waves hide the image loads.
+#ifndef PWC_IMAGE_CONV_WAVES
+#define PWC_IMAGE_CONV_WAVES 8
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PWC_IMAGE_CONV_WAVES, 8)))
 image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                      _Float16 *__restrict__ y, int H, int W, int Ho, int Wo, int64_t npix, int64_t bsx, int64_t bsy,
                      float slope) {
@@ -227,7 +233,10 @@ image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, c
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = 2 * ox - 1 + kx;
-                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((int64_t)ci * H + iy) * W + ix] : 0.f;
+                // unconditional load from the clamped address + select: no divergent branch per tap
+                const bool ok = (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+                const float ld = xb[((int64_t)ci * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+                const float v = ok ? ld : 0.f;
                 const float4 *wr = reinterpret_cast<const float4 *>(sw[(ci * 3 + ky) * 3 + kx]);      // 4 broadcast b128 reads
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
