@@ -21,6 +21,7 @@
 // Needs W % 4 == 0, W >= 128 and 16-byte aligned tensors; the dispatchers in pwc_conv.hip / pwc_deconv.hip
 // use other kernels otherwise.
 #include "pwc_common.h"
+#include <cstdlib>
 
 #ifdef PWC_STREAM_NT_LOAD          // experiment: stream the arena with the non-temporal policy
 #define PWC_STREAM_DMA pwc::dma_b128_nt
@@ -34,26 +35,38 @@ using pwc::leaky;
 
 constexpr int kCK = 4;                  // channels per chunk
 constexpr int kRing = 3;                // 72 KiB -> two workgroups per CU (a 4th slot measured slower: one WG/CU)
-constexpr int kTH = 8;
 constexpr int kTW = 128;
-constexpr int kThreads = 256;              // consumer threads (4 waves); a 5th wave runs the DMA ring
-constexpr int kBlockThreads = 320;
-constexpr int kRows = kTH + 2;
 constexpr int kPitch = kTW + 8;         // floats: cols x0-4 .. x0+131
 constexpr int kQuads = kPitch / 4;      // 34 pieces per row
-constexpr int kPieces = kCK * kRows * kQuads;                   // 1360
-constexpr int kSlots = (kPieces + kThreads - 1) / kThreads;     // 6 x 256 pieces per ring slot
-constexpr int kInstr = kSlots * 4;                              // 24 x 1-KiB strips per ring slot: 22 tile strips + 2 tap strips
-constexpr int kVmem = kInstr + 2;                               // VMEM instructions per chunk: 22 x b128 + 4 x b32 (taps)
-constexpr int kBuf = kSlots * kThreads * 4;                     // 6144 floats = 24 KiB per ring slot
-constexpr int kHeadWOff = (kSlots - 1) * kThreads * 4 + 2 * 256;    // floats: wave 2's last-slot strip (5632)
-constexpr int kUpWOff = (kSlots - 1) * kThreads * 4 + 3 * 256;      // floats: wave 3's last-slot strip (5888)
 constexpr int kHeadWRow = 20;           // global: {co0: 9 taps, 0, co1: 9 taps, 0} per channel; LDS: [tap][co] + 2 zeros
 constexpr int kUpWRow = 32;             // global: nn layout [ci][co][4][4]; LDS: [ky*4+kx][co]
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kOOB = 0x80000000u;
 static_assert(kRing == 3, "the loader's counted wait assumes exactly one younger chunk in flight");
-static_assert(kPieces * 4 <= kHeadWOff, "weights strip overlaps the tile");
+
+// Tile geometry.  TH rows x 128 columns per workgroup; KS consumer groups of TH*32 threads share the tile, group k
+// accumulating channels k*(4/KS).. of every chunk (partial sums meet in LDS after the last chunk).  <8,1> is the
+// streaming shape for large maps; <4,4> quarters the per-wave fma chain and doubles the workgroup count for maps that
+// give fewer than 256 tiles (level 3 at batch 16: 112 -> 224 workgroups, 2 waves per SIMD instead of 1).
+template <int TH, int KS>
+struct Cfg {
+    static constexpr int kTH = TH, kKS = KS;
+    static constexpr int kPix = TH * 32;                     // threads per group; thread = 4 consecutive pixels
+    static constexpr int kThreads = kPix * KS;               // consumer threads; one more wave runs the DMA ring
+    static constexpr int kLoaderWave = kThreads / 64;
+    static constexpr int kBlockThreads = kThreads + 64;
+    static constexpr int kRows = TH + 2;
+    static constexpr int kPieces = kCK * kRows * kQuads;     // 16-byte pieces of one chunk's tile (1360 for TH = 8)
+    static constexpr int kTileInstr = (kPieces + 63) / 64;   // 1-KiB strips (= DMA instructions) carrying the tile (22)
+    static constexpr int kInstr = kTileInstr + 2;            // + one strip of head taps + one of upfeat taps
+    static constexpr int kVmem = kInstr + 2;                 // VMEM instructions per chunk: tile b128s + 4 x b32 (taps)
+    static constexpr int kBuf = kInstr * 256;                // floats per ring slot (24 KiB for TH = 8)
+    static constexpr int kHeadWOff = kTileInstr * 256;       // floats
+    static constexpr int kUpWOff = (kTileInstr + 1) * 256;
+    static constexpr int kCPerGroup = kCK / KS;
+    static_assert(kPix % 64 == 0 && kCK % KS == 0, "groups are whole waves and split the chunk evenly");
+    static_assert(kPieces * 4 <= kHeadWOff, "weights strip overlaps the tile");
+};
 
 constexpr int MODE_HEAD = 1, MODE_UPFEAT = 2;
 
@@ -61,9 +74,10 @@ constexpr int MODE_HEAD = 1, MODE_UPFEAT = 2;
 // dword DMAs carry the taps into strips 22 (head, 80 floats) and 23 (upfeat, 128 floats), re-ordered to [tap][co]
 // by their per-lane source offsets (woff).  A mode that is off still issues its two (all out-of-range) DMAs so that
 // the counted vmcnt is the same for every instantiation.
-template <int MODE>
+template <int MODE, typename G>
 __device__ __forceinline__ void issue(const float *xb, const float *hw, const float *uw, int chunk, int Cin, int plane,
-                                      float *buf, const unsigned (&off)[kInstr - 2], const unsigned (&woff)[4]) {
+                                      float *buf, const unsigned (&off)[G::kTileInstr], const unsigned (&woff)[4]) {
+    constexpr int kInstr = G::kInstr;
     const int c0 = chunk * kCK;
     const int cvalid = min(kCK, Cin - c0);
     const pwc::v4i32 r = pwc::make_rsrc(xb + (int64_t)c0 * plane, cvalid * plane * 4);
@@ -78,8 +92,8 @@ __device__ __forceinline__ void issue(const float *xb, const float *hw, const fl
     pwc::dma_b32(ru, base + (kInstr - 1) * 1024 + 256, woff[3]);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(kBlockThreads)
+template <int MODE, int TH, int KS>
+__global__ void __launch_bounds__((Cfg<TH, KS>::kBlockThreads))
 stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x, int tiles_y, int64_t bsx,
                  // HEAD: w packed [Cin][20], y [B,2,H,W]
                  const float *__restrict__ hw, const float *__restrict__ hbias, const float *__restrict__ residual,
@@ -87,13 +101,19 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
                  // UPFEAT: w [Cin][2][16], y [B,2,2H,2W]
                  const float *__restrict__ uw, const float *__restrict__ ubias, float *__restrict__ uy, int64_t bsuy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    using G = Cfg<TH, KS>;
+    constexpr int kTH = G::kTH, kRows = G::kRows, kPieces = G::kPieces, kTileInstr = G::kTileInstr, kVmem = G::kVmem;
+    constexpr int kBuf = G::kBuf, kHeadWOff = G::kHeadWOff, kUpWOff = G::kUpWOff, kPix = G::kPix;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int ty = tid >> 5;            // 0..7  row inside the tile
-    const int tx = tid & 31;            // 0..31 group of 4 pixels
+    const int grp = __builtin_amdgcn_readfirstlane(tid / kPix);     // consumer group (channel slice of every chunk)
+    const int t = tid % kPix;
+    const int ty = t >> 5;              // row inside the tile
+    const int tx = t & 31;              // 0..31 group of 4 pixels
     int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // an XCD takes a contiguous run of tiles
     const int bx = bid % tiles_x;
     bid /= tiles_x;
     const int by = bid % tiles_y;
@@ -105,14 +125,14 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
     const float *xb = x + (int64_t)b * bsx;
     const int nchunks = (Cin + kCK - 1) / kCK;
 
-    if (wave == 4) {
+    if (wave == G::kLoaderWave) {
         // ================= producer wave: runs the ring, two chunks ahead of the consumers ==================
 #ifndef PWC_STREAM_NO_PRIO
         __builtin_amdgcn_s_setprio(3);     // as in the correlation kernel: the ring's issue slots come first
 #endif
-        unsigned off[kInstr - 2];
+        unsigned off[kTileInstr];
 #pragma unroll
-        for (int i = 0; i < kInstr - 2; ++i) {
+        for (int i = 0; i < kTileInstr; ++i) {
             const int p = i * 64 + lane;
             const int c = p / (kRows * kQuads);
             const int rem = p % (kRows * kQuads);
@@ -141,13 +161,17 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
         }
 #pragma unroll
         for (int k = 0; k < kRing - 1; ++k)
-            if (k < nchunks) issue<MODE>(xb, hw, uw, k, Cin, plane, smem + k * kBuf, off, woff);
+            if (k < nchunks) issue<MODE, G>(xb, hw, uw, k, Cin, plane, smem + k * kBuf, off, woff);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             if (chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kVmem) : "memory");   // kRing == 3
             else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // consumers may read slot chunk%3; they are done with (chunk-1)%3
             if (chunk + kRing - 1 < nchunks)
-                issue<MODE>(xb, hw, uw, chunk + kRing - 1, Cin, plane, smem + ((chunk + kRing - 1) % kRing) * kBuf, off, woff);
+                issue<MODE, G>(xb, hw, uw, chunk + kRing - 1, Cin, plane, smem + ((chunk + kRing - 1) % kRing) * kBuf, off, woff);
+        }
+        if constexpr (KS > 1) {            // the two barriers of the consumers' reduction
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
         }
         return;
     }
@@ -167,7 +191,8 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
         const float *cur = smem + (chunk % kRing) * kBuf;
         // channels past Cin in the last chunk: tile AND taps were range-checked to 0, so they add exactly 0
 #pragma unroll
-        for (int c = 0; c < kCK; ++c) {
+        for (int cc = 0; cc < G::kCPerGroup; ++cc) {
+            const int c = grp * G::kCPerGroup + cc;
             const float *t = cur + (c * kRows + ty) * kPitch + 4 * tx + 3;     // window col -1
             float v[3][6];
 #pragma unroll
@@ -229,6 +254,44 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS reads done before the ring slot is refilled
     }
 
+    if constexpr (KS > 1) {
+        // partial sums of groups 1.. -> LDS (the ring is free once every consumer passed the first barrier) -> group 0
+        constexpr int kAcc = ((MODE & MODE_HEAD) ? 8 : 0) + ((MODE & MODE_UPFEAT) ? 32 : 0);
+        constexpr int kHeadAcc = (MODE & MODE_HEAD) ? 8 : 0;
+        __builtin_amdgcn_s_barrier();
+        if (grp > 0) {
+            float *red = smem + (grp - 1) * kAcc * kPix + t;
+            if constexpr (MODE & MODE_HEAD) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { red[(2 * p) * kPix] = hacc[p][0]; red[(2 * p + 1) * kPix] = hacc[p][1]; }
+            }
+            if constexpr (MODE & MODE_UPFEAT) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    red[(kHeadAcc + 2 * j) * kPix] = uacc[j >> 3][j & 7][0];
+                    red[(kHeadAcc + 2 * j + 1) * kPix] = uacc[j >> 3][j & 7][1];
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        if (grp > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const float *red = smem + (k - 1) * kAcc * kPix + t;
+            if constexpr (MODE & MODE_HEAD) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { hacc[p][0] += red[(2 * p) * kPix]; hacc[p][1] += red[(2 * p + 1) * kPix]; }
+            }
+            if constexpr (MODE & MODE_UPFEAT) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    uacc[j >> 3][j & 7][0] += red[(kHeadAcc + 2 * j) * kPix];
+                    uacc[j >> 3][j & 7][1] += red[(kHeadAcc + 2 * j + 1) * kPix];
+                }
+            }
+        }
+    }
+
     const int oy = y0 + ty;
     const int ox = x0 + 4 * tx;
     if (oy >= H || ox >= W) return;
@@ -263,22 +326,45 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
     }
 }
 
+template <int MODE, int TH, int KS>
+int launch_cfg(const float *x, int B, int Cin, int H, int W, int64_t bsx,
+               const float *hw, const float *hbias, const float *residual, float *hy, int64_t bshy, int64_t bsr,
+               float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
+    using G = Cfg<TH, KS>;
+    const int tiles_x = (W + kTW - 1) / kTW;
+    const int tiles_y = (H + TH - 1) / TH;
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "stream3x3: grid too large");
+    constexpr int kAcc = ((MODE & MODE_HEAD) ? 8 : 0) + ((MODE & MODE_UPFEAT) ? 32 : 0);
+    constexpr int ring = kRing * G::kBuf * 4, red = (KS - 1) * kAcc * G::kPix * 4;
+    constexpr int smem = ring > red ? ring : red;
+    auto kern = stream3x3_kernel<MODE, TH, KS>;
+    static pwc::LdsAttrOnce attr;       // per instantiation, tracked per device
+    if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), smem, "stream3x3")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(G::kBlockThreads), smem, st,
+                       x, Cin, H, W, tiles_x, tiles_y, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky,
+                       uw, ubias, uy, bsuy);
+    return pwc::check_launch("stream3x3_kernel");
+}
+
+// PWC_STREAM_CFG=81|42|44 pins the tile shape (experiments); default: <4,4> when 8-row tiles would leave CUs idle.
+inline int stream_cfg_override() {
+    static const int v = [] { const char *e = getenv("PWC_STREAM_CFG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <int MODE>
 int launch(const float *x, int B, int Cin, int H, int W, int64_t bsx,
            const float *hw, const float *hbias, const float *residual, float *hy, int64_t bshy, int64_t bsr,
            float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
-    const int tiles_x = (W + kTW - 1) / kTW;
-    const int tiles_y = (H + kTH - 1) / kTH;
-    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
-    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "stream3x3: grid too large");
-    constexpr int smem = kRing * kBuf * 4;      // 96 KiB
-    auto kern = stream3x3_kernel<MODE>;
-    static pwc::LdsAttrOnce attr;       // per instantiation, tracked per device
-    if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), smem, "stream3x3")) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kBlockThreads), smem, st,
-                       x, Cin, H, W, tiles_x, tiles_y, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky,
-                       uw, ubias, uy, bsuy);
-    return pwc::check_launch("stream3x3_kernel");
+    const int64_t nblk8 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8);
+    int cfg = stream_cfg_override();
+    if (cfg != 81 && cfg != 42 && cfg != 44) cfg = nblk8 < 256 ? 44 : 81;
+#define PWC_STREAM_GO(TH, KS) return launch_cfg<MODE, TH, KS>(x, B, Cin, H, W, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky, uw, ubias, uy, bsuy, st)
+    if (cfg == 44) PWC_STREAM_GO(4, 4);
+    if (cfg == 42) PWC_STREAM_GO(4, 2);
+    PWC_STREAM_GO(8, 1);
+#undef PWC_STREAM_GO
 }
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -290,7 +376,7 @@ namespace pwc_conv {
 // true when the streaming kernel applies to this geometry (the callers keep their other kernels otherwise)
 bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx) {
     return (W % 4 == 0) && (W >= 128) && al16(x) && (bsx % 4 == 0) && ((int64_t)H * W * kCK * 4 < 0x7fffffffLL) &&
-           (int64_t)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH) >= 64;
+           (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8) >= 64;
 }
 
 // w = packed head taps [Cin][20] (tail of pwc_conv3x3_pack's buffer for Cout == 2)

@@ -21,6 +21,9 @@ def short(n):
          re.search(r"conv3x3_f16_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", n))
     if m:
         return "f16conv<MT%s,NT%s,S%s,D%s,R%s>" % m.groups()
+    m = re.search(r"stream3x3_kernel<(\d+), (\d+), (\d+)>", n)
+    if m:
+        return "stream3x3<mode%s,TH%s,KS%s>" % m.groups()
     for k in ("corr81_c8", "warp_c8", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
         if k in n:
             return k
