@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 2
+#define PWC_ABI_VERSION 3
 
 /* element types */
 #define PWC_F32 0
@@ -148,6 +148,19 @@ int pwc_corr81_c8_f16(const void *in1, const void *in2, void *out, int B, int C,
 int pwc_warp_c8_f16(const void *x, const void *flo, void *out, int B, int C, int H, int W, int flo_channel,
                     float flow_scale, int align_corners, float mask_threshold,
                     int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride, void *stream);
+/* Entry of decoder level L < 6 on c8 f16 tensors in one pass (reference models/PWCNet.py:208-212, 222-226, 236-240,
+ * 252-256: up_flow = deconv(flow), up_feat = upfeat(x), warp = self.warp(c2L, up_flow * s), then the concat):
+ *   flow_phases, feat_phases: [B][1][H/2][W/2][8] -- the two transposed convs computed as 3x3 convs with 4 output
+ *     phases per channel (pwc_conv2d_f16_fwd), channel index co*4 + py*2 + px;
+ *   flow_group [B][1][H][W][8]: channels 0,1 <- up_flow, 2,3 <- up_feat (4..7 untouched) -- the arena's last group;
+ *   c1_dst <- c1 (ceil(C/8) groups: the arena's c1 slot);  warped <- warp(c2, up_flow * flow_scale) as pwc_warp_c8_f16.
+ * H and W must be even. */
+int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void *flow_phases, const void *feat_phases,
+                           void *c1_dst, void *flow_group, void *warped, int B, int C, int H, int W,
+                           float flow_scale, int align_corners, float mask_threshold,
+                           int64_t c1_bstride, int64_t c2_bstride, int64_t flow_phases_bstride,
+                           int64_t feat_phases_bstride, int64_t c1_dst_bstride, int64_t flow_group_bstride,
+                           int64_t warped_bstride, void *stream);
 
 /* ConvTranspose2d(kernel 4, stride 2, padding 1) + bias.  x:[B,Cin,H,W], w:[Cin,Cout,4,4] (nn layout),
  * y:[B,Cout,2H,2W]. */

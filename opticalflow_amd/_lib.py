@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
 LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
@@ -50,6 +50,7 @@ SIGNATURES = {
                                   c_int64, c_int64, c_int64, c_void_p]),
     "pwc_warp_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float,
                                 c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_level_entry_c8_f16": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float, c_int, c_float] + [c_int64] * 7 + [c_void_p]),
     "pwc_deconv4x4s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_head_upfeat_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

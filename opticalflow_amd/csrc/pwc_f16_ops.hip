@@ -14,6 +14,7 @@
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -145,18 +146,47 @@ corr81_c8_direct_kernel(const _Float16 *__restrict__ in1, const _Float16 *__rest
 }
 
 // ---- warp ---------------------------------------------------------------------------------------------------
+// ENTRY = the whole entry of a decoder level in one pass (pwc_level_entry_c8_f16): up_flow / up_feat arrive as the
+// 4-phase output of the 3x3 form of the transposed convs ([B][1][H/2][W/2][8], channel co*4 + py*2 + px); the thread
+// picks its phase, writes (up_flow, up_feat) into channels 0..3 of the arena's flow group, copies its pixel of c1
+// into the arena and warps with the up_flow it already holds.
+struct LevelEntry {
+    const _Float16 *flow_phases, *feat_phases, *c1;
+    _Float16 *fg, *c1_dst;
+    int64_t bs_flowp, bs_featp, bs_c1, bs_fg, bs_c1dst;
+};
+
+template <bool ENTRY>
 __global__ void __launch_bounds__(256)
 warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo, _Float16 *__restrict__ out,
                int Cg, int H, int W, int64_t npix, int flo_channel, int64_t bsx, int64_t bsf, int64_t bso,
-               float flow_scale, int align_corners, float thr) {
+               float flow_scale, int align_corners, float thr, LevelEntry e) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
     const int64_t plane = (int64_t)H * W;
     const int b = (int)(i / plane);
     const int pix = (int)(i - (int64_t)b * plane);
     const int yy = pix / W, xx = pix - yy * W;
-    const _Float16 *f = flo + (int64_t)b * bsf + (int64_t)pix * 8 + flo_channel;
-    const float u = (float)f[0] * flow_scale, v = (float)f[1] * flow_scale;
+    float u, v;
+    if constexpr (ENTRY) {
+        const int64_t sp = ((int64_t)(yy >> 1) * (W >> 1) + (xx >> 1)) * 8;
+        const int ph = (yy & 1) * 2 + (xx & 1);
+        const h8 pf = *reinterpret_cast<const h8 *>(e.flow_phases + (int64_t)b * e.bs_flowp + sp);
+        const h8 pq = *reinterpret_cast<const h8 *>(e.feat_phases + (int64_t)b * e.bs_featp + sp);
+        h4 o;
+        o[0] = pf[ph]; o[1] = pf[4 + ph]; o[2] = pq[ph]; o[3] = pq[4 + ph];
+        *reinterpret_cast<h4 *>(e.fg + (int64_t)b * e.bs_fg + (int64_t)pix * 8) = o;
+        u = (float)o[0] * flow_scale;
+        v = (float)o[1] * flow_scale;
+        const _Float16 *cs = e.c1 + (int64_t)b * e.bs_c1 + (int64_t)pix * 8;
+        _Float16 *cd = e.c1_dst + (int64_t)b * e.bs_c1dst + (int64_t)pix * 8;
+        for (int g = 0; g < Cg; ++g, cs += plane * 8, cd += plane * 8)
+            *reinterpret_cast<h8 *>(cd) = *reinterpret_cast<const h8 *>(cs);
+    } else {
+        const _Float16 *f = flo + (int64_t)b * bsf + (int64_t)pix * 8 + flo_channel;
+        u = (float)f[0] * flow_scale;
+        v = (float)f[1] * flow_scale;
+    }
     // same arithmetic as pwc_warp.hip::make_taps (PWCNet.py:162-163 + grid_sample's un-normalisation)
     const float gx = 2.0f * ((float)xx + u) / (float)max(W - 1, 1) - 1.0f;
     const float gy = 2.0f * ((float)yy + v) / (float)max(H - 1, 1) - 1.0f;
@@ -315,9 +345,39 @@ extern "C" int pwc_warp_c8_f16(const void *x, const void *flo, void *out, int B,
     const int64_t npix = (int64_t)B * H * W;
     const int64_t nblk = (npix + 255) / 256;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_warp_c8_f16: grid too large");
-    hipLaunchKernelGGL(warp_c8_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(warp_c8_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const _Float16 *>(x), static_cast<const _Float16 *>(flo), static_cast<_Float16 *>(out),
                        (C + 7) / 8, H, W, npix, flo_channel, x_bstride, flo_bstride, out_bstride,
-                       flow_scale, align_corners, mask_threshold);
+                       flow_scale, align_corners, mask_threshold, LevelEntry{});
     return pwc::check_launch("warp_c8_kernel");
+}
+
+extern "C" int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void *flow_phases, const void *feat_phases,
+                                      void *c1_dst, void *flow_group, void *warped, int B, int C, int H, int W,
+                                      float flow_scale, int align_corners, float mask_threshold,
+                                      int64_t c1_bstride, int64_t c2_bstride, int64_t flow_phases_bstride,
+                                      int64_t feat_phases_bstride, int64_t c1_dst_bstride, int64_t flow_group_bstride,
+                                      int64_t warped_bstride, void *stream) {
+    if (!c1 || !c2 || !flow_phases || !feat_phases || !c1_dst || !flow_group || !warped)
+        PWC_FAIL(PWC_EINVAL, "pwc_level_entry_c8_f16: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
+        PWC_FAIL(PWC_EINVAL, "pwc_level_entry_c8_f16: H and W must be positive and even (twice the level above), got %dx%d", H, W);
+    const void *ptrs[7] = {c1, c2, flow_phases, feat_phases, c1_dst, flow_group, warped};
+    const int64_t strides[7] = {c1_bstride, c2_bstride, flow_phases_bstride, feat_phases_bstride, c1_dst_bstride,
+                                flow_group_bstride, warped_bstride};
+    for (int k = 0; k < 7; ++k)
+        if (!pwc::aligned16(ptrs[k]) || (strides[k] % 8))
+            PWC_FAIL(PWC_EALIGN, "pwc_level_entry_c8_f16: tensors must be 16-byte aligned with batch strides that are multiples of 8");
+    if (c2 == warped || c1 == c1_dst) PWC_FAIL(PWC_EINVAL, "pwc_level_entry_c8_f16: in-place operands");
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t nblk = (npix + 255) / 256;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_level_entry_c8_f16: grid too large");
+    LevelEntry e{static_cast<const _Float16 *>(flow_phases), static_cast<const _Float16 *>(feat_phases),
+                 static_cast<const _Float16 *>(c1), static_cast<_Float16 *>(flow_group), static_cast<_Float16 *>(c1_dst),
+                 flow_phases_bstride, feat_phases_bstride, c1_bstride, flow_group_bstride, c1_dst_bstride};
+    hipLaunchKernelGGL(warp_c8_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16 *>(c2), static_cast<const _Float16 *>(nullptr), static_cast<_Float16 *>(warped),
+                       (C + 7) / 8, H, W, npix, 0, c2_bstride, (int64_t)0, warped_bstride,
+                       flow_scale, align_corners, mask_threshold, e);
+    return pwc::check_launch("warp_c8_kernel<entry>");
 }

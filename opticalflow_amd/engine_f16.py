@@ -228,10 +228,12 @@ class PwcPlanF16:
             if l == 6:
                 F16.correlation_c8(c1, c2, PYRAMID_CH[6], normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
             else:
+                # one launch: pixel-shuffle deconv / upfeat of the level above into the flow group, c1 into the arena, warp
                 f0 = BASE_G + CORR_G
-                ar[:, f0:f0 + g].copy_(c1)
-                F16.warp_c8(c2, ar[:, f0 + g:f0 + g + 1], PYRAMID_CH[l], flo_channel=0, flow_scale=WARP_SCALE[l],
-                            align_corners=self.align_corners, mask_threshold=self.mask_threshold, out=self.warped[l])
+                F16.level_entry(c1, c2, self.upflow[l + 1], self.head[l + 1][:, 1:2], PYRAMID_CH[l],
+                                c1_dst=ar[:, f0:f0 + g], flow_group=ar[:, f0 + g:f0 + g + 1], out=self.warped[l],
+                                flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
+                                mask_threshold=self.mask_threshold)
                 F16.correlation_c8(c1, self.warped[l], PYRAMID_CH[l], normalize=self.normalize_corr, leaky_slope=LEAKY,
                                    out=corr_slot)
             lo = BASE_G
@@ -240,11 +242,7 @@ class PwcPlanF16:
                 lo = og
             self._conv("head%d" % l, ar, self.head[l], act=False)
             if l > 2:
-                self._conv("deconv%d" % l, self.head[l][:, 0:1], self.upflow[l], act=False)
-                nxt = self.arena[l - 1]
-                fg = nxt[:, nxt.shape[1] - 1]                     # the flow group of the next level [B,2h,2w,8]
-                self._shuffle(self.upflow[l][:, 0], fg[..., 0:2])
-                self._shuffle(self.head[l][:, 1], fg[..., 2:4])
+                self._conv("deconv%d" % l, self.head[l][:, 0:1], self.upflow[l], act=False)   # 4 phases; shuffled by level_entry
         t = self.arena[2]
         for i, (_, dil) in enumerate(CONTEXT):
             self._conv("dc_conv%d" % (i + 1), t, self.ctx[i], dilation=dil)

@@ -152,6 +152,30 @@ def warp_c8(x: torch.Tensor, flo: torch.Tensor, channels: int, flo_channel: int 
     return out
 
 
+def level_entry(c1: torch.Tensor, c2: torch.Tensor, flow_phases: torch.Tensor, feat_phases: torch.Tensor, channels: int,
+                c1_dst: torch.Tensor, flow_group: torch.Tensor, out: torch.Tensor, flow_scale: float = 1.0,
+                align_corners: bool = False, mask_threshold: float = 0.9999) -> torch.Tensor:
+    """Entry of a decoder level in one launch (PWCNet.py:208-212): pixel-shuffle the 4-phase transposed-conv outputs
+    `flow_phases` / `feat_phases` [B,1,H/2,W/2,8] into channels 0..3 of `flow_group` [B,1,H,W,8], copy c1 into
+    `c1_dst`, and write warp(c2, up_flow * flow_scale) to `out`."""
+    lib = _lib.load()
+    B, cg, H, W, _ = c2.shape
+    if cg != (channels + 7) // 8 or c1.shape != c2.shape or c1_dst.shape != c2.shape or out.shape != c2.shape:
+        raise ValueError("c1, c2, c1_dst, out must all be [B,%d,H,W,8]" % ((channels + 7) // 8))
+    if H % 2 or W % 2 or tuple(flow_phases.shape) != (B, 1, H // 2, W // 2, 8) or feat_phases.shape != flow_phases.shape \
+            or tuple(flow_group.shape) != (B, 1, H, W, 8):
+        raise ValueError("phase tensors must be [B,1,H/2,W/2,8] and flow_group [B,1,H,W,8]")
+    strides = [_c8_bstride(t, n) for t, n in ((c1, "c1"), (c2, "c2"), (flow_phases, "flow_phases"), (feat_phases, "feat_phases"),
+                                              (c1_dst, "c1_dst"), (flow_group, "flow_group"), (out, "out"))]
+    with torch.cuda.device(c2.device):
+        rc = lib.pwc_level_entry_c8_f16(c1.data_ptr(), c2.data_ptr(), flow_phases.data_ptr(), feat_phases.data_ptr(),
+                                        c1_dst.data_ptr(), flow_group.data_ptr(), out.data_ptr(), B, channels, H, W,
+                                        float(flow_scale), 1 if align_corners else 0, float(mask_threshold),
+                                        *strides, _stream(c2))
+    check(rc, "pwc_level_entry_c8_f16")
+    return out
+
+
 def image_conv_s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, leaky_slope: float = 0.1,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv1a (Conv2d(3,16,3,stride 2,pad 1) + LeakyReLU) from a float32 [B,3,H,W] image (dense planes, free batch

@@ -151,6 +151,38 @@ def test_warp_c8_vs_oracle(dev, align, thr):
     assert torch.equal(_to_c8_cpu(x), F16.to_c8(x.to(dev)).cpu())
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 21, 14, 34), (1, 32, 8, 6), (3, 128, 28, 64)])
+def test_level_entry_equals_shuffle_copy_warp(dev, B, C, H, W):
+    """pwc_level_entry_c8_f16 (one launch) == pixel shuffle of both 4-phase tensors + c1 copy + pwc_warp_c8_f16, bit for bit;
+    operands are batch-strided slices of larger buffers as in the plan's arena."""
+    from opticalflow_amd import ops_f16 as F16
+    from opticalflow_amd.engine_f16 import PwcPlanF16
+    g = (C + 7) // 8
+    c1 = F16.to_c8(seeded_rand((B, C, H, W), 560, -1, 1).to(dev))
+    c2 = F16.to_c8(seeded_rand((B, C, H, W), 561, -1, 1).to(dev))
+    heads = (seeded_rand((B, 2, H // 2, W // 2, 8), 562, -3, 3).half().to(dev))    # group 1 = upfeat phases (head[l][:, 1:2])
+    flowp = (seeded_rand((B, 1, H // 2, W // 2, 8), 563, -3, 3).half().to(dev))    # deconv phases (upflow[l])
+    def fresh():
+        arena = torch.full((B, 3 + g + 1, H, W, 8), 0.25, dtype=torch.float16, device=dev)
+        arena[:, 3 + g] = 0
+        return arena, torch.zeros_like(c2)
+    a_ref, w_ref = fresh()
+    a_ref[:, 3:3 + g].copy_(c1)
+    fg = a_ref[:, 3 + g]
+    PwcPlanF16._shuffle(flowp[:, 0], fg[..., 0:2])
+    PwcPlanF16._shuffle(heads[:, 1], fg[..., 2:4])
+    F16.warp_c8(c2, a_ref[:, 3 + g:4 + g], C, flo_channel=0, flow_scale=1.25, out=w_ref)
+    a_got, w_got = fresh()
+    F16.level_entry(c1, c2, flowp, heads[:, 1:2], C, c1_dst=a_got[:, 3:3 + g], flow_group=a_got[:, 3 + g:4 + g], out=w_got,
+                    flow_scale=1.25)
+    torch.cuda.synchronize()
+    assert torch.equal(a_got, a_ref) and torch.equal(w_got, w_ref)
+    assert (a_got[:, :3] == 0.25).all() and (a_got[:, 3 + g, ..., 4:] == 0).all()
+    with pytest.raises(Exception):
+        F16.level_entry(c1[:, :, :H - 1], c2[:, :, :H - 1], flowp, heads[:, 1:2], C, c1_dst=a_got[:, 3:3 + g, :H - 1],
+                        flow_group=a_got[:, 3 + g:4 + g, :H - 1], out=w_got[:, :, :H - 1])
+
+
 def test_forward_fp16_vs_reference_golden(dev):
     """Whole network with half-precision activations/filters (fp32 accumulation) vs the reference's fp32 output on the
     golden inputs.  Bar: mean EPE <= 1e-2 * mean |flow|; observed ~1e-3 relative."""

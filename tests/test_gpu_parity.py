@@ -331,10 +331,14 @@ def test_deconv_vs_torch_cpu(dev, cin, geom):
     assert (out[:, :2] == 0).all() and (out[:, 4:] == 0).all()
 
 
-def test_streaming_head_deconv_and_fused_entry(dev):
-    """Wide levels take the LDS-ring streaming kernel (pwc_stream3x3.hip): head, upfeat and the fused call."""
+@pytest.mark.parametrize("geom", [(8, 149, 58, 128),     # 64 8-row tiles -> <TH4,KS4> (4 channel groups + LDS sum), ragged rows
+                                  (32, 149, 60, 128),    # 256 8-row tiles -> <TH8,KS1>, ragged rows (60 = 7.5 tiles)
+                                  (8, 37, 34, 132)])     # two tile columns, the second 4 px wide; ragged rows
+def test_streaming_head_deconv_and_fused_entry(dev, geom):
+    """Wide levels take the LDS-ring streaming kernel (pwc_stream3x3.hip): head, upfeat and the fused call.
+    Every case has a ragged last channel chunk (cin % 4 == 1)."""
     from opticalflow_amd import ops
-    B, cin, H, W = 8, 149, 60, 128            # 8 * 8 tiles >= 64, ragged rows (60 = 7.5 tiles), ragged channel chunk
+    B, cin, H, W = geom
     assert ops.head_upfeat_supported(B, H, W)
     x = seeded_rand((B, cin, H, W), 110, -1, 1)
     hw = seeded_rand((2, cin, 3, 3), 111, -1, 1) * 0.05
