@@ -507,6 +507,11 @@ constexpr bool variant_valid(int mt, int nt, int two) {
     return false;
 }
 
+inline bool tune_l2() {        // PWC_CONV_NO_TUNE_L2=1: the cost model without the measured level-2 residuals (A/B runs)
+    static const bool on = [] { const char *e = getenv("PWC_CONV_NO_TUNE_L2"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 template <int S, int D>
 inline TileChoice choose_tile(int B, int Cin, int Ho, int Wo, int CoutP, int max_nt, int max_mt, int force_two) {
     const int tiles32 = CoutP / 32;
@@ -538,6 +543,14 @@ inline TileChoice choose_tile(int B, int Cin, int Ho, int Wo, int CoutP, int max
                     if (mt == 3) cost *= 1.12;                      // measured: the 96-wide variant under-performs here
                 }
                 cost *= 1.0 + 0.02 * (groups - 1);               // mild penalty: input re-read per cout group
+                if (S == 1 && two && blocks > 512.0 && tune_l2()) {
+                    // measured residuals of the model on the level-2 layers at batch 16 (19-variant sweep after the
+                    // XCD-aware tile order, profiles/r01_conv_notes.md): 8-row tiles halve the halo share of the
+                    // staging for 32-cout layers and for dilation 4; with dilation 16 the 4-row tile wins
+                    if (D == 1 && tiles32 == 1 && nt == 1) cost *= 1.045;
+                    if (D == 4 && nt == 1) cost *= 1.04;
+                    if (D == 16 && nt > 1) cost *= 1.05;
+                }
                 if (cost < best_cost) { best_cost = cost; best = {mt, nt, two}; }
             }
         }
