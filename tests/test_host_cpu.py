@@ -41,6 +41,11 @@ def test_abi_argument_errors_without_gpu():
     assert lib.pwc_conv3x3_packed_bytes(32, 2, 0) == (4 * 8 * 9 * 32 + 32 * 20) * 4      # MFMA image + [Cin][20] head tail
     assert lib.pwc_conv3x3_packed_bytes(0, 2, 0) == -1
     assert lib.pwc_conv3x3_packed_bytes(8, 8, 1) == -1          # f16 weights not supported
+    # decoder level entry: the level must be exactly twice the level above (PWCNet.py:208-212 needs even H, W)
+    fake = [ctypes.c_void_p(4096)] * 7
+    assert lib.pwc_level_entry_c8_f16(*fake, 1, 32, 7, 16, 1.25, 0, 0.9999, *([8] * 7), None) == -1
+    assert b"even" in lib.pwc_last_error()
+    assert lib.pwc_level_entry_c8_f16(None, *fake[1:], 1, 32, 8, 16, 1.25, 0, 0.9999, *([8] * 7), None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
