@@ -290,6 +290,11 @@ int launch16(const Args16 &a) {
 // Tile choice: widest cout tile that fits the LDS, 3-slot ring if possible, else 2 slots; 16-row tiles (NT = 4) for
 // stride-1 layers with >= 64 couts once the grid is large enough to keep every CU busy with them.
 // PWC_CONV16F_MT / PWC_CONV16F_RING / PWC_CONV16F_NT override (tuning).
+inline bool skip_uneven() {      // PWC_CONV16F_UNEVEN=1 keeps the 96 + 32 split (A/B runs)
+    static const bool on = [] { const char *e = getenv("PWC_CONV16F_UNEVEN"); return !(e && e[0] == '1'); }();
+    return on;
+}
+
 template <int S, int D>
 int dispatch16(const Args16 &a) {
     static const int forced_mt = [] { const char *e = getenv("PWC_CONV16F_MT"); return (e && *e) ? atoi(e) : 0; }();
@@ -302,7 +307,10 @@ int dispatch16(const Args16 &a) {
     const int64_t tiles8 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 7) / 8);
     static const int kFillBlocks = [] { const char *e = getenv("PWC_CONV16F_FILL"); return (e && *e) ? atoi(e) : 256; }();
     if (forced_mt <= 0)
-        while (want > 1 && tiles8 * ((t32 + want - 1) / want) < kFillBlocks) --want;
+        while (want > 1 && tiles8 * ((t32 + want - 1) / want) < kFillBlocks) {
+            --want;
+            if (want == 3 && t32 == 4 && skip_uneven()) want = 2;      // 128 couts as 96 + 32: the wide group finishes last
+        }
     // short K (<= 12 chunks = 192 input channels: conv2_0, dc_conv2/3, the pyramid): a workgroup's prologue and epilogue
     // are a large share of its life, so prefer 64-cout tiles with a 2-slot ring -- two workgroups then share a CU and
     // cover each other (conv2_0 177 -> 142 us, dc_conv2 190 -> 150 us at batch 16; long-K layers lose with it)
