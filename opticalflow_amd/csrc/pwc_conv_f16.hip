@@ -306,8 +306,9 @@ int dispatch16(const Args16 &a) {
     // bound by its DMA round trips instead of MT x as many MFMAs, and the tiny input is simply re-read per cout group
     const int64_t tiles8 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 7) / 8);
     static const int kFillBlocks = [] { const char *e = getenv("PWC_CONV16F_FILL"); return (e && *e) ? atoi(e) : 256; }();
+    static const int kFillBlocksD1 = [] { const char *e = getenv("PWC_CONV16F_FILL_D1"); return (e && *e) ? atoi(e) : 1024; }();   // dilation-1 layers: narrow tiles up to 1024 workgroups (measured below)
     if (forced_mt <= 0)
-        while (want > 1 && tiles8 * ((t32 + want - 1) / want) < kFillBlocks) {
+        while (want > 1 && tiles8 * ((t32 + want - 1) / want) < ((D == 1 && S == 1) ? kFillBlocksD1 : kFillBlocks)) {
             --want;
             if (want == 3 && t32 == 4 && skip_uneven()) want = 2;      // 128 couts as 96 + 32: the wide group finishes last
         }
