@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 3
+#define PWC_ABI_VERSION 4
 
 /* element types */
 #define PWC_F32 0
@@ -52,6 +52,11 @@ extern "C" {
                                  multiplying by corr_multiply (correlation.py:35-36)              */
 #define PWC_ACT_LEAKY 2u      /* fuse LeakyReLU(slope) into the epilogue (PWCNet.py:72,199)          */
 #define PWC_CONV_RESIDUAL 4u  /* y += residual (flow2 + dc_conv7(...), PWCNet.py:268)                */
+/* pwc_conv2d_f16_fwd only */
+#define PWC_CONV_OUT_F32 8u   /* y is float [B][ceil(Cout/8)][Ho][Wo][8] instead of half (flow heads: the values that
+                                 carry the flow from level to level stay in fp32)                    */
+#define PWC_CONV_SPLIT_W 16u  /* wp comes from pwc_conv3x3_f16_pack_split (Cout <= 16): ~22-bit filters at no extra
+                                 MFMA cost, for the 2-channel heads                                  */
 
 int pwc_abi_version(void);
 const char *pwc_last_error(void);
@@ -118,12 +123,16 @@ int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int s
 /* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------
  * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch
  * stride (in halves, multiple of 8) is free, so a tensor may be a channel-group slice of an arena.  fp32
- * accumulation on v_mfma_f32_32x32x16_f16; bias fp32; optional LeakyReLU; output rounded to half.
+ * accumulation on v_mfma_f32_32x32x16_f16; bias fp32; optional LeakyReLU; output rounded to half with saturation
+ * (|v| > 65504 -> +-65504, never inf), or left in fp32 with PWC_CONV_OUT_F32.
  * Same operator as pwc_conv2d_fwd (nn.Conv2d 3x3 + LeakyReLU, PWCNet.py:26-33): stride 1 with dilation 1,2,4,8,16 and
  * stride 2 with dilation 1 (PWC_EUNSUPPORTED otherwise; no residual flag). */
 int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout);
 /* w: [Cout,Cin,3,3] f32 (nn.Conv2d layout, device) -> wp: packed halves [Cg/2][tap][2][CoutP][8]. */
 int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream);
+/* Same size and layout for Cout <= 16 with the 16 unused rows of the 32-row cout tile carrying the rounding residual
+ * of each filter (times 2^11): y = sum(hi) + sum(lo)/2^11 in the epilogue of pwc_conv2d_f16_fwd(PWC_CONV_SPLIT_W). */
+int pwc_conv3x3_f16_pack_split(const void *w, void *wp, int Cin, int Cout, void *stream);
 int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
                        int B, int Cin, int H, int W, int Cout, int stride, int dilation,
                        unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream);
@@ -149,16 +158,22 @@ int pwc_warp_c8_f16(const void *x, const void *flo, void *out, int B, int C, int
                     float flow_scale, int align_corners, float mask_threshold,
                     int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride, void *stream);
 /* Entry of decoder level L < 6 on c8 f16 tensors in one pass (reference models/PWCNet.py:208-212, 222-226, 236-240,
- * 252-256: up_flow = deconv(flow), up_feat = upfeat(x), warp = self.warp(c2L, up_flow * s), then the concat):
- *   flow_phases, feat_phases: [B][1][H/2][W/2][8] -- the two transposed convs computed as 3x3 convs with 4 output
- *     phases per channel (pwc_conv2d_f16_fwd), channel index co*4 + py*2 + px;
- *   flow_group [B][1][H][W][8]: channels 0,1 <- up_flow, 2,3 <- up_feat (4..7 untouched) -- the arena's last group;
- *   c1_dst <- c1 (ceil(C/8) groups: the arena's c1 slot);  warped <- warp(c2, up_flow * flow_scale) as pwc_warp_c8_f16.
- * H and W must be even. */
-int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void *flow_phases, const void *feat_phases,
+ * 252-256: up_flow = deconv(flow), up_feat = upfeat(x), warp = self.warp(c2L, up_flow * s), then the concat).
+ * The flow stays in fp32 from level to level:
+ *   flow32: float [B][>=1][H/2][W/2][8] -- the level above's head convolution run with PWC_CONV_OUT_F32, flow (u,v) in
+ *     channels 0,1;  deconv_w [2,2,4,4] / deconv_b [2] float: deconvL's nn.ConvTranspose2d parameters, applied here in
+ *     fp32 (16 fma per output value);
+ *   feat_phases: float [B][1][H/2][W/2][8] -- upfeatL computed as a 3x3 conv with 4 output phases per channel
+ *     (pwc_conv2d_f16_fwd), channel index co*4 + py*2 + px;
+ *   flow_group [B][1][H][W][8] halves: channels 0,1 <- up_flow, 2,3 <- up_feat (4..7 untouched) -- the arena's last group;
+ *   c1_dst <- c1 (ceil(C/8) groups: the arena's c1 slot);  warped <- warp(c2, up_flow * flow_scale) with the fp32
+ *     up_flow, taps and mask as pwc_warp_c8_f16.
+ * H and W must be even.  Batch strides in elements of the tensor's own type. */
+int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void *flow32, const void *feat_phases,
+                           const void *deconv_w, const void *deconv_b,
                            void *c1_dst, void *flow_group, void *warped, int B, int C, int H, int W,
                            float flow_scale, int align_corners, float mask_threshold,
-                           int64_t c1_bstride, int64_t c2_bstride, int64_t flow_phases_bstride,
+                           int64_t c1_bstride, int64_t c2_bstride, int64_t flow32_bstride,
                            int64_t feat_phases_bstride, int64_t c1_dst_bstride, int64_t flow_group_bstride,
                            int64_t warped_bstride, void *stream);
 

@@ -13,11 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
 LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
 FLAG_CONV_RESIDUAL = 4
+FLAG_CONV_OUT_F32 = 8
+FLAG_CONV_SPLIT_W = 16
 
 # name -> (restype, argtypes); mirrors include/pwc_hip.h one to one
 SIGNATURES = {
@@ -40,6 +42,7 @@ SIGNATURES = {
     "pwc_conv2d_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "pwc_conv3x3_f16_packed_bytes": (c_int64, [c_int, c_int]),
     "pwc_conv3x3_f16_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pwc_conv3x3_f16_pack_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pwc_conv2d_f16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),
     "pwc_nchw_to_c8_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
@@ -50,7 +53,7 @@ SIGNATURES = {
                                   c_int64, c_int64, c_int64, c_void_p]),
     "pwc_warp_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float,
                                 c_int64, c_int64, c_int64, c_void_p]),
-    "pwc_level_entry_c8_f16": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_float, c_int, c_float] + [c_int64] * 7 + [c_void_p]),
+    "pwc_level_entry_c8_f16": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_int, c_float] + [c_int64] * 7 + [c_void_p]),
     "pwc_deconv4x4s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_head_upfeat_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -33,6 +33,10 @@ template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return
 
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// float -> half with saturation: a value past the half range becomes +-65504 instead of inf (which the next layer's
+// fp32 accumulation would turn into NaN through inf - inf); NaN stays NaN
+__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Raise a kernel's dynamic-LDS limit once per (kernel instantiation, device).  `done` is a per-instantiation

@@ -27,6 +27,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBlock = 320;          // waves 0..3: MFMA, wave 4: loader
+constexpr int kModeLeaky = 1, kModeOutF32 = 2, kModeSplitW = 4;
+
 constexpr int kTileW = 32;
 constexpr unsigned kOOB = 0x80000000u;
 
@@ -71,8 +73,8 @@ __device__ __forceinline__ void issue_f16(const _Float16 *xb, const _Float16 *wp
 template <int MT, int NT, int S, int D, int R>
 __global__ void __launch_bounds__(kBlock)
 conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp, const float *__restrict__ bias,
-                   _Float16 *__restrict__ y, int Cg, int H, int W, int Cout, int CoutP, int Ho, int Wo,
-                   int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int do_leaky) {
+                   void *__restrict__ yv, int Cg, int H, int W, int Cout, int CoutP, int Ho, int Wo,
+                   int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int mode) {
     using G = G16<MT, NT, S, D, R>;
     constexpr int kNT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -134,13 +136,15 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     // ================= MFMA waves: wave w owns rows 2w, 2w+1 of the tile ======================================
     const int col = lane & 31;
     const int kh = lane >> 5;
+    const bool do_leaky = mode & kModeLeaky, out_f32 = mode & kModeOutF32, split_w = mode & kModeSplitW;
     f32x16 acc[MT][kNT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-            const float bv = bias[min(co, Cout - 1)];
+            float bv = bias[min(co, Cout - 1)];
+            if (split_w && j >= 8) bv = 0.f;              // rows 16..31 carry the low halves of the filters: no bias
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) acc[mt][nt][j] = bv;
         }
@@ -183,22 +187,34 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
             for (int q = 0; q < 4; ++q) {
                 const int cg = (g * G::kCoutT + mt * 32) / 8 + q;
                 if (cg >= cg_out) continue;
-                h4 o;
+                float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v = acc[mt][nt][4 * q + i];
-                    if (do_leaky) v = pwc::leaky(v, slope);
-                    o[i] = (cg * 8 + 4 * kh + i < Cout) ? (_Float16)v : (_Float16)0.f;
+                    v[i] = acc[mt][nt][4 * q + i];
+                    // split filters (Cout <= 16): row co + 16 = sum over the low halves scaled by 2^11 (q < 2 always here)
+                    if (split_w) v[i] += acc[mt][nt][(4 * q + i + 8) & 15] * (1.0f / 2048.0f);
+                    if (do_leaky) v[i] = pwc::leaky(v[i], slope);
+                    if (cg * 8 + 4 * kh + i >= Cout) v[i] = 0.f;
                 }
-                *reinterpret_cast<h4 *>(y + (int64_t)b * bsy + ((int64_t)cg * oplane + (int64_t)oy * Wo + ox) * 8 + 4 * kh) = o;
+                const int64_t at = (int64_t)b * bsy + ((int64_t)cg * oplane + (int64_t)oy * Wo + ox) * 8 + 4 * kh;
+                if (out_f32) {
+                    *reinterpret_cast<float4 *>(static_cast<float *>(yv) + at) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    h4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = pwc::sat_half(v[i]);
+                    *reinterpret_cast<h4 *>(static_cast<_Float16 *>(yv) + at) = o;
+                }
             }
         }
     }
 }
 
 // wp[cgp][tap][kh][CoutP][8] <- w[co][ci = 8*(2*cgp + kh) + j][tap]   (zero outside Cin / Cout)
+// split = 1 (Cout <= 16, CoutP = 32): row co holds the filter rounded to half, row co + 16 the rounding residual
+// times 2^11 (exact scaling; keeps it out of the subnormal range), so that hi + lo / 2^11 carries ~22 bits of the filter
 __global__ void __launch_bounds__(256)
-pack3x3_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int Cin, int Cout, int CoutP, int64_t total) {
+pack3x3_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int Cin, int Cout, int CoutP, int64_t total, int split) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int j = (int)(i & 7);
@@ -211,8 +227,10 @@ pack3x3_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int C
     const int cgp = (int)(t / 9);
     const int ci = 8 * (2 * cgp + kh) + j;
     float v = 0.f;
-    if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * 9 + tap];
-    wp[i] = (_Float16)v;
+    const int cs = split ? (co & 15) : co;
+    if (cs < Cout && ci < Cin) v = w[((int64_t)cs * Cin + ci) * 9 + tap];
+    const _Float16 hi = pwc::sat_half(v);
+    wp[i] = (split && co >= 16) ? (_Float16)((v - (float)hi) * 2048.0f) : hi;
 }
 
 // [B][C][H][W] f32 -> [B][Cg][H][W][8] f16 (zero channel padding) and back
@@ -229,7 +247,7 @@ nchw_to_c8_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = cg * 8 + j;
-        o[j] = (c < C) ? (_Float16)x[b * bsx + (int64_t)c * plane + pix] : (_Float16)0.f;
+        o[j] = (c < C) ? pwc::sat_half(x[b * bsx + (int64_t)c * plane + pix]) : (_Float16)0.f;
     }
     *reinterpret_cast<h8 *>(y + b * bsy + ((int64_t)cg * plane + pix) * 8) = o;
 }
@@ -254,11 +272,11 @@ c8_to_nchw_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, int C, 
 struct Args16 {
     const _Float16 *x, *wp;
     const float *bias;
-    _Float16 *y;
+    void *y;
     int B, Cg, H, W, Cout, CoutP, Ho, Wo;
     int64_t bsx, bsy;
     float slope;
-    int do_leaky;
+    int mode;
     hipStream_t stream;
 };
 
@@ -282,7 +300,7 @@ int launch16(const Args16 &a) {
         const int smem = (nchunks < R ? nchunks : R) * G::kSlotBytes;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), smem, a.stream,
                            a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo, tiles_x, tiles_y,
-                           a.bsx, a.bsy, a.slope, a.do_leaky);
+                           a.bsx, a.bsy, a.slope, a.mode);
         return pwc::check_launch("conv3x3_f16_kernel");
     }
 }
@@ -302,6 +320,7 @@ int dispatch16(const Args16 &a) {
     static const int forced_nt = [] { const char *e = getenv("PWC_CONV16F_NT"); return (e && *e) ? atoi(e) : 0; }();
     const int t32 = a.CoutP / 32;
     int want = forced_mt > 0 ? min(forced_mt, t32) : min(t32, 4);
+    if (a.mode & kModeSplitW) want = 1;
     // small grids (levels 6-4, batch-1 inference): narrower cout tiles = more workgroups; a workgroup's K loop is then
     // bound by its DMA round trips instead of MT x as many MFMAs, and the tiny input is simply re-read per cout group
     const int64_t tiles8 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 7) / 8);
@@ -352,14 +371,23 @@ extern "C" int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout) {
     return (int64_t)((cg + 1) / 2) * 18 * cout_padded(Cout) * 16;
 }
 
-extern "C" int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream) {
-    if (!w || !wp) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_f16_pack: null pointer");
-    if (Cin <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_f16_pack: bad shape");
-    if (!pwc::aligned16(wp)) PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_f16_pack: packed buffer must be 16-byte aligned");
+static int pack_f16(const void *w, void *wp, int Cin, int Cout, void *stream, int split, const char *who) {
+    if (!w || !wp) PWC_FAIL(PWC_EINVAL, "%s: null pointer", who);
+    if (Cin <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "%s: bad shape", who);
+    if (split && Cout > 16) PWC_FAIL(PWC_EUNSUPPORTED, "%s: split filters need Cout <= 16 (got %d)", who, Cout);
+    if (!pwc::aligned16(wp)) PWC_FAIL(PWC_EALIGN, "%s: packed buffer must be 16-byte aligned", who);
     const int64_t total = pwc_conv3x3_f16_packed_bytes(Cin, Cout) / 2;
     hipLaunchKernelGGL(pack3x3_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float *>(w), static_cast<_Float16 *>(wp), Cin, Cout, cout_padded(Cout), total);
+                       static_cast<const float *>(w), static_cast<_Float16 *>(wp), Cin, Cout, cout_padded(Cout), total, split);
     return pwc::check_launch("pack3x3_f16_kernel");
+}
+
+extern "C" int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream) {
+    return pack_f16(w, wp, Cin, Cout, stream, 0, "pwc_conv3x3_f16_pack");
+}
+
+extern "C" int pwc_conv3x3_f16_pack_split(const void *w, void *wp, int Cin, int Cout, void *stream) {
+    return pack_f16(w, wp, Cin, Cout, stream, 1, "pwc_conv3x3_f16_pack_split");
 }
 
 extern "C" int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride,
@@ -392,6 +420,7 @@ extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bia
     if (!pwc::aligned16(x) || !pwc::aligned16(y) || !pwc::aligned16(wp) || (x_bstride % 8) || (y_bstride % 8))
         PWC_FAIL(PWC_EALIGN, "pwc_conv2d_f16_fwd: tensors must be 16-byte aligned with batch strides that are multiples of 8");
     if (flags & PWC_CONV_RESIDUAL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: residual is not implemented for fp16");
+    if ((flags & PWC_CONV_SPLIT_W) && Cout > 16) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: split filters need Cout <= 16 (got %d)", Cout);
     const int64_t plane = (int64_t)H * W;
     const int cg = (Cin + 7) / 8;
     if (x_bstride < (int64_t)cg * plane * 8) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: x batch stride < Cg*H*W*8");
@@ -400,13 +429,14 @@ extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bia
     a.x = static_cast<const _Float16 *>(x);
     a.wp = static_cast<const _Float16 *>(wp);
     a.bias = static_cast<const float *>(bias);
-    a.y = static_cast<_Float16 *>(y);
+    a.y = y;
     a.B = B; a.Cg = cg; a.H = H; a.W = W; a.Cout = Cout; a.CoutP = cout_padded(Cout);
     a.Ho = (H - 1) / stride + 1;
     a.Wo = (W - 1) / stride + 1;
     a.bsx = x_bstride; a.bsy = y_bstride;
     a.slope = leaky_slope;
-    a.do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
+    a.mode = ((flags & PWC_ACT_LEAKY) ? kModeLeaky : 0) | ((flags & PWC_CONV_OUT_F32) ? kModeOutF32 : 0) |
+             ((flags & PWC_CONV_SPLIT_W) ? kModeSplitW : 0);
     a.stream = static_cast<hipStream_t>(stream);
     if (stride == 1) {
         switch (dilation) {

@@ -109,7 +109,7 @@ corr81_c8_kernel(const _Float16 *__restrict__ in1, const _Float16 *__restrict__ 
                 v = acc[d < 81 ? d : 0] * scale;
                 if (do_leaky) v = pwc::leaky(v, slope);
             }
-            o[j] = (_Float16)v;
+            o[j] = pwc::sat_half(v);
         }
         *reinterpret_cast<h8 *>(po + (int64_t)g * plane * 8) = o;
     }
@@ -142,19 +142,23 @@ corr81_c8_direct_kernel(const _Float16 *__restrict__ in1, const _Float16 *__rest
         acc *= scale;
         if (do_leaky) acc = pwc::leaky(acc, slope);
     }
-    out[(int64_t)b * bso + ((int64_t)(d >> 3) * plane + pix) * 8 + (d & 7)] = (_Float16)acc;
+    out[(int64_t)b * bso + ((int64_t)(d >> 3) * plane + pix) * 8 + (d & 7)] = pwc::sat_half(acc);
 }
 
 // ---- warp ---------------------------------------------------------------------------------------------------
-// ENTRY = the whole entry of a decoder level in one pass (pwc_level_entry_c8_f16): up_flow / up_feat arrive as the
-// 4-phase output of the 3x3 form of the transposed convs ([B][1][H/2][W/2][8], channel co*4 + py*2 + px); the thread
-// picks its phase, writes (up_flow, up_feat) into channels 0..3 of the arena's flow group, copies its pixel of c1
-// into the arena and warps with the up_flow it already holds.
+// ENTRY = the whole entry of a decoder level in one pass (pwc_level_entry_c8_f16).  The flow travels in fp32:
+// `flow32` is the fp32 c8 output of the level above's head convolution (channels 0,1 of its group), the thread
+// applies deconvL (ConvTranspose2d(2,2,k4,s2,p1), PWCNet.py:84,208) to it in fp32 -- 2x2 input pixels x 2 channels per
+// output -- and warps with that fp32 up_flow; up_feat arrives as the 4-phase fp32 output of the 3x3 form of upfeatL
+// (channel co*4 + py*2 + px).  (up_flow, up_feat) are also written, rounded to half, into channels 0..3 of the
+// arena's flow group (they are inputs of the level's convolutions), and the thread copies its pixel of c1 into the arena.
 struct LevelEntry {
-    const _Float16 *flow_phases, *feat_phases, *c1;
+    const float *flow32, *feat_phases, *dw, *db;       // dw: [ci 2][co 2][ky 4][kx 4] (nn.ConvTranspose2d layout), db: [2]
+    const _Float16 *c1;
     _Float16 *fg, *c1_dst;
-    int64_t bs_flowp, bs_featp, bs_c1, bs_fg, bs_c1dst;
+    int64_t bs_flow, bs_featp, bs_c1, bs_fg, bs_c1dst;
 };
+
 
 template <bool ENTRY>
 __global__ void __launch_bounds__(256)
@@ -169,15 +173,34 @@ warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo,
     const int yy = pix / W, xx = pix - yy * W;
     float u, v;
     if constexpr (ENTRY) {
-        const int64_t sp = ((int64_t)(yy >> 1) * (W >> 1) + (xx >> 1)) * 8;
-        const int ph = (yy & 1) * 2 + (xx & 1);
-        const h8 pf = *reinterpret_cast<const h8 *>(e.flow_phases + (int64_t)b * e.bs_flowp + sp);
-        const h8 pq = *reinterpret_cast<const h8 *>(e.feat_phases + (int64_t)b * e.bs_featp + sp);
+        const int hh = H >> 1, wh = W >> 1;
+        const int py = yy & 1, px = xx & 1;
+        // output row 2Y+py takes input rows r0 = Y-1+py (kernel row 3-py) and r0+1 (kernel row 1-py); same along x
+        const int r0 = (yy >> 1) - 1 + py, c0 = (xx >> 1) - 1 + px;
+        const float *fb = e.flow32 + (int64_t)b * e.bs_flow;
+        float acc0 = e.db[0], acc1 = e.db[1];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int r = r0 + a, ky = 3 - py - 2 * a;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int cc = c0 + c, kx = 3 - px - 2 * c;
+                if (r < 0 || r >= hh || cc < 0 || cc >= wh) continue;
+                const float2 f = *reinterpret_cast<const float2 *>(fb + ((int64_t)r * wh + cc) * 8);
+                acc0 = fmaf(f.x, e.dw[(0 * 2 + 0) * 16 + ky * 4 + kx], acc0);
+                acc0 = fmaf(f.y, e.dw[(1 * 2 + 0) * 16 + ky * 4 + kx], acc0);
+                acc1 = fmaf(f.x, e.dw[(0 * 2 + 1) * 16 + ky * 4 + kx], acc1);
+                acc1 = fmaf(f.y, e.dw[(1 * 2 + 1) * 16 + ky * 4 + kx], acc1);
+            }
+        }
+        const int64_t sp = ((int64_t)(yy >> 1) * wh + (xx >> 1)) * 8;
+        const int ph = py * 2 + px;
+        const float *pq = e.feat_phases + (int64_t)b * e.bs_featp + sp;
         h4 o;
-        o[0] = pf[ph]; o[1] = pf[4 + ph]; o[2] = pq[ph]; o[3] = pq[4 + ph];
+        o[0] = pwc::sat_half(acc0); o[1] = pwc::sat_half(acc1); o[2] = pwc::sat_half(pq[ph]); o[3] = pwc::sat_half(pq[4 + ph]);
         *reinterpret_cast<h4 *>(e.fg + (int64_t)b * e.bs_fg + (int64_t)pix * 8) = o;
-        u = (float)o[0] * flow_scale;
-        v = (float)o[1] * flow_scale;
+        u = acc0 * flow_scale;
+        v = acc1 * flow_scale;
         const _Float16 *cs = e.c1 + (int64_t)b * e.bs_c1 + (int64_t)pix * 8;
         _Float16 *cd = e.c1_dst + (int64_t)b * e.bs_c1dst + (int64_t)pix * 8;
         for (int g = 0; g < Cg; ++g, cs += plane * 8, cd += plane * 8)
@@ -281,7 +304,7 @@ image_conv_s2_kernel(const float *__restrict__ x, const float *__restrict__ w, c
     for (int g = 0; g < 2; ++g) {
         h8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (_Float16)pwc::leaky(acc[g * 4 + j / 2][j & 1], slope);
+        for (int j = 0; j < 8; ++j) o[j] = pwc::sat_half(pwc::leaky(acc[g * 4 + j / 2][j & 1], slope));
         *reinterpret_cast<h8 *>(yo + (int64_t)g * oplane * 8) = o;
     }
 }
@@ -352,18 +375,19 @@ extern "C" int pwc_warp_c8_f16(const void *x, const void *flo, void *out, int B,
     return pwc::check_launch("warp_c8_kernel");
 }
 
-extern "C" int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void *flow_phases, const void *feat_phases,
+extern "C" int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void *flow32, const void *feat_phases,
+                                      const void *deconv_w, const void *deconv_b,
                                       void *c1_dst, void *flow_group, void *warped, int B, int C, int H, int W,
                                       float flow_scale, int align_corners, float mask_threshold,
-                                      int64_t c1_bstride, int64_t c2_bstride, int64_t flow_phases_bstride,
+                                      int64_t c1_bstride, int64_t c2_bstride, int64_t flow32_bstride,
                                       int64_t feat_phases_bstride, int64_t c1_dst_bstride, int64_t flow_group_bstride,
                                       int64_t warped_bstride, void *stream) {
-    if (!c1 || !c2 || !flow_phases || !feat_phases || !c1_dst || !flow_group || !warped)
+    if (!c1 || !c2 || !flow32 || !feat_phases || !deconv_w || !deconv_b || !c1_dst || !flow_group || !warped)
         PWC_FAIL(PWC_EINVAL, "pwc_level_entry_c8_f16: null pointer");
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
         PWC_FAIL(PWC_EINVAL, "pwc_level_entry_c8_f16: H and W must be positive and even (twice the level above), got %dx%d", H, W);
-    const void *ptrs[7] = {c1, c2, flow_phases, feat_phases, c1_dst, flow_group, warped};
-    const int64_t strides[7] = {c1_bstride, c2_bstride, flow_phases_bstride, feat_phases_bstride, c1_dst_bstride,
+    const void *ptrs[7] = {c1, c2, flow32, feat_phases, c1_dst, flow_group, warped};
+    const int64_t strides[7] = {c1_bstride, c2_bstride, flow32_bstride, feat_phases_bstride, c1_dst_bstride,
                                 flow_group_bstride, warped_bstride};
     for (int k = 0; k < 7; ++k)
         if (!pwc::aligned16(ptrs[k]) || (strides[k] % 8))
@@ -372,9 +396,10 @@ extern "C" int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void
     const int64_t npix = (int64_t)B * H * W;
     const int64_t nblk = (npix + 255) / 256;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_level_entry_c8_f16: grid too large");
-    LevelEntry e{static_cast<const _Float16 *>(flow_phases), static_cast<const _Float16 *>(feat_phases),
+    LevelEntry e{static_cast<const float *>(flow32), static_cast<const float *>(feat_phases),
+                 static_cast<const float *>(deconv_w), static_cast<const float *>(deconv_b),
                  static_cast<const _Float16 *>(c1), static_cast<_Float16 *>(flow_group), static_cast<_Float16 *>(c1_dst),
-                 flow_phases_bstride, feat_phases_bstride, c1_bstride, flow_group_bstride, c1_dst_bstride};
+                 flow32_bstride, feat_phases_bstride, c1_bstride, flow_group_bstride, c1_dst_bstride};
     hipLaunchKernelGGL(warp_c8_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const _Float16 *>(c2), static_cast<const _Float16 *>(nullptr), static_cast<_Float16 *>(warped),
                        (C + 7) / 8, H, W, npix, 0, c2_bstride, (int64_t)0, warped_bstride,

@@ -10,7 +10,13 @@
   * the 2-channel layers as MFMA convolutions: ``predict_flowL`` and ``upfeatL`` read the same 3x3 windows, and a
     ConvTranspose2d(k4, s2, p1) is a 3x3 convolution with 4 output phases per channel followed by a pixel shuffle
     (PWCNet.py:35-36), so head + upfeat are ONE convolution with 16 output channels (flow in group 0, the 8 upfeat
-    phases in group 1) and ``deconvL`` is a second one on the flow group; the shuffles are strided copies.
+    phases in group 1);
+  * the FLOW CHAIN IN FP32: the values that carry the flow from level to level (PWCNet.py:207-212,268) never pass
+    through half.  The head convolutions (and dc_conv7) leave their result in float32 and use split filters
+    (hi + residual in the idle half of the 32-row cout tile: ~22-bit filters at no extra MFMA cost); ``deconvL``
+    (2 -> 2 channels) is applied in fp32 inside the level-entry kernel, which warps with that fp32 up_flow; the final
+    ``flow2 + dc_conv7(...)`` is an fp32 add.  Only the COPY of (up_flow, up_feat) that the next level's convolutions
+    read as 4 of their ~500 input channels is rounded to half.  Every store to half saturates at +-65504.
 
 No autograd (like the fp32 plan); training mode returns the 5-tuple via ``flows()``.  ``variant="old"`` (PWCDCNet_old, PWCNet.py:277-491) first brings that model's filters into
 PWCDCNet's concatenation order (engine.old_variant_perm), skips the ``*aa`` pyramid convs and uses the 0.999 mask
@@ -22,6 +28,7 @@ from typing import Dict
 
 import torch
 
+from . import ops
 from . import ops_f16 as F16
 from .engine import (CONTEXT, DENSE_OUT, LEAKY, PYRAMID_CH, PYRAMID_NAMES, PYRAMID_NAMES_OLD, WARP_SCALE, level_in_channels,
                      old_variant_perm)
@@ -90,19 +97,17 @@ class PwcPlanF16:
             g = _groups(PYRAMID_CH[l])
             self.pyr_a[l] = torch.zeros((self._slots(B), g, h, w, 8), **hk)
             self.pyr_b[l] = torch.zeros((self._slots(B), g, h, w, 8), **hk)
-        self.arena, self.warped, self.head, self.upflow = {}, {}, {}, {}
+        self.arena, self.warped, self.head = {}, {}, {}
         for l in range(2, 7):
             h, w = self.size[l]
             g = _groups(PYRAMID_CH[l])
             self.arena[l] = torch.zeros((B, BASE_G + CORR_G + (g + 1 if l < 6 else 0), h, w, 8), **hk)
             if l < 6:
                 self.warped[l] = torch.zeros((B, g, h, w, 8), **hk)
-            self.head[l] = torch.zeros((B, 2 if l > 2 else 1, h, w, 8), **hk)
-            if l > 2:
-                self.upflow[l] = torch.zeros((B, 1, h, w, 8), **hk)
+            self.head[l] = torch.zeros((B, 2 if l > 2 else 1, h, w, 8), device=device, dtype=torch.float32)
         h2, w2 = self.size[2]
         self.ctx = [torch.zeros((B, _groups(c), h2, w2, 8), **hk) for c, _ in CONTEXT]
-        self.dc7 = torch.zeros((B, 1, h2, w2, 8), **hk)
+        self.dc7 = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
         self.flow_out = torch.empty((B, 2, h2, w2), device=device, dtype=torch.float32)
 
         # ---- filters: re-index to the physical channel order, pad, pack --------------------------------------------
@@ -110,9 +115,15 @@ class PwcPlanF16:
         self.b: Dict[str, torch.Tensor] = {}
         self.cin: Dict[str, int] = {}
         self.cout: Dict[str, int] = {}
+        self.deconv_w: Dict[int, torch.Tensor] = {}
+        self.deconv_b: Dict[int, torch.Tensor] = {}
 
-        def put(name, w, bias):
-            self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float())
+        self.split = set()
+
+        def put(name, w, bias, split=False):
+            self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float(), split=split)
+            if split:
+                self.split.add(name)
             self.b[name] = bias.contiguous().float()
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
 
@@ -157,16 +168,17 @@ class PwcPlanF16:
                 bias = bh.new_zeros(16)
                 bias[0:2] = bh
                 bias[8:16] = p["upfeat%d.bias" % l].repeat_interleave(4)
-                put("head%d" % l, remap(k, 0, 0), bias)
-                wd = _deconv_as_conv3x3(p["deconv%d.weight" % l])            # [8, 2, 3, 3]
-                put("deconv%d" % l, _pad_cin(wd, 8), p["deconv%d.bias" % l].repeat_interleave(4))
+                put("head%d" % l, remap(k, 0, 0), bias, split=True)
+                # deconvL (2 -> 2 channels) runs in fp32 inside the level-entry kernel: raw ConvTranspose2d parameters
+                self.deconv_w[l] = p["deconv%d.weight" % l].contiguous()
+                self.deconv_b[l] = p["deconv%d.bias" % l].contiguous()
             else:
-                put("head2", remap(wh, 0, 0), bh)
+                put("head2", remap(wh, 0, 0), bh, split=True)
                 put("dc_conv1", remap(p["dc_conv1.0.weight"], 0, 0), p["dc_conv1.0.bias"])
         for i in range(2, 7):
             w = p["dc_conv%d.0.weight" % i]
             put("dc_conv%d" % i, _pad_cin(w, _groups(w.shape[1]) * 8), p["dc_conv%d.0.bias" % i])
-        put("dc_conv7", _pad_cin(p["dc_conv7.weight"], 32), p["dc_conv7.bias"])
+        put("dc_conv7", _pad_cin(p["dc_conv7.weight"], 32), p["dc_conv7.bias"], split=True)
 
     @staticmethod
     def _slots(B: int) -> int:
@@ -175,14 +187,8 @@ class PwcPlanF16:
     # ---- primitives -------------------------------------------------------------------------------------------------
     def _conv(self, name, x, out, stride=1, dilation=1, act=True):
         F16.conv3x3_f16(x, self.w[name], self.b[name], self.cin[name], self.cout[name], stride=stride, dilation=dilation,
-                        leaky_slope=LEAKY if act else None, out=out)
-
-    @staticmethod
-    def _shuffle(phases: torch.Tensor, dst: torch.Tensor) -> None:
-        """phases [B,h,w,8] (channel = co*4 + py*2 + px) -> dst [B,2h,2w,2] (strided view into a flow group)."""
-        B, h, w, _ = phases.shape
-        # one strided copy: dst[b, 2y+py, 2x+px, co] = phases[b, y, x, co, py, px]
-        dst.view(B, h, 2, w, 2, 2).copy_(phases.view(B, h, w, 2, 2, 2).permute(0, 1, 4, 2, 5, 3))
+                        leaky_slope=LEAKY if act else None, out=out, out_f32=out.dtype == torch.float32,
+                        split_w=name in self.split)
 
     # ---- the forward ----------------------------------------------------------------------------------------------------
     def run(self, x: torch.Tensor) -> torch.Tensor:
@@ -190,12 +196,13 @@ class PwcPlanF16:
         if tuple(x.shape) != (B, 6, self.H, self.W) or x.dtype != torch.float32 or x.device != self.device:
             raise ValueError("plan built for float32 %s on %s, got %s %s on %s" % (
                 (B, 6, self.H, self.W), self.device, x.dtype, tuple(x.shape), x.device))
+        x = ops.densify(x)
         self._pyramid([(x[:, :3], 0, B), (x[:, 3:], B, 2 * B)], 0, 2 * B)
         return self._decode()
 
     def flows(self):
         """(flow2, flow3, flow4, flow5, flow6) of the last run as float32 NCHW -- the training-mode return (PWCNet.py:270-271)."""
-        return (self.flow_out,) + tuple(self.head[l][:, 0, :, :, 0:2].permute(0, 3, 1, 2).float() for l in (3, 4, 5, 6))
+        return (self.flow_out,) + tuple(self.head[l][:, 0, :, :, 0:2].permute(0, 3, 1, 2).contiguous() for l in (3, 4, 5, 6))
 
     def _pair_views(self, l: int):
         """first / second image's level features as views of the pyramid buffer"""
@@ -230,7 +237,8 @@ class PwcPlanF16:
             else:
                 # one launch: pixel-shuffle deconv / upfeat of the level above into the flow group, c1 into the arena, warp
                 f0 = BASE_G + CORR_G
-                F16.level_entry(c1, c2, self.upflow[l + 1], self.head[l + 1][:, 1:2], PYRAMID_CH[l],
+                F16.level_entry(c1, c2, self.head[l + 1][:, 0:1], self.head[l + 1][:, 1:2], self.deconv_w[l + 1],
+                                self.deconv_b[l + 1], PYRAMID_CH[l],
                                 c1_dst=ar[:, f0:f0 + g], flow_group=ar[:, f0 + g:f0 + g + 1], out=self.warped[l],
                                 flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
                                 mask_threshold=self.mask_threshold)
@@ -240,9 +248,7 @@ class PwcPlanF16:
             for i, og in enumerate(DENSE_G):
                 self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, og:og + DENSE_OUT[i] // 8])
                 lo = og
-            self._conv("head%d" % l, ar, self.head[l], act=False)
-            if l > 2:
-                self._conv("deconv%d" % l, self.head[l][:, 0:1], self.upflow[l], act=False)   # 4 phases; shuffled by level_entry
+            self._conv("head%d" % l, ar, self.head[l], act=False)     # float32 out: flow (+ the 8 upfeat phases)
         t = self.arena[2]
         for i, (_, dil) in enumerate(CONTEXT):
             self._conv("dc_conv%d" % (i + 1), t, self.ctx[i], dilation=dil)
@@ -275,7 +281,7 @@ class PwcVideoPlanF16(PwcPlanF16):
         if tuple(frames.shape) != (n, 3, self.H, self.W) or frames.dtype != torch.float32 or frames.device != self.device:
             raise ValueError("expected float32 frames %s on %s, got %s %s on %s" % (
                 (n, 3, self.H, self.W), self.device, frames.dtype, tuple(frames.shape), frames.device))
-        return frames.contiguous()
+        return ops.densify(frames)
 
     def _carry(self) -> None:
         for l in range(2, 7):

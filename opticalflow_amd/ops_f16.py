@@ -27,10 +27,10 @@ def c8_shape(B: int, C: int, H: int, W: int):
     return (B, (C + 7) // 8, H, W, 8)
 
 
-def _c8_bstride(t: torch.Tensor, name: str) -> int:
+def _c8_bstride(t: torch.Tensor, name: str, dtype: torch.dtype = torch.float16) -> int:
     """c8 tensors must have dense [Cg,H,W,8] planes; the batch stride is free (channel-group slices of an arena)."""
-    if t.dim() != 5 or t.shape[4] != 8 or t.dtype != torch.float16:
-        raise ValueError("%s must be a float16 [B,Cg,H,W,8] tensor, got %s %s" % (name, t.dtype, tuple(t.shape)))
+    if t.dim() != 5 or t.shape[4] != 8 or t.dtype != dtype:
+        raise ValueError("%s must be a %s [B,Cg,H,W,8] tensor, got %s %s" % (name, dtype, t.dtype, tuple(t.shape)))
     _require_device(t, name)
     _, cg, h, w, _ = t.shape
     if t.stride()[1:] != (h * w * 8, w * 8, 8, 1):
@@ -69,35 +69,46 @@ def from_c8(x: torch.Tensor, channels: int) -> torch.Tensor:
     return out
 
 
-def pack_conv3x3_f16(weight: torch.Tensor) -> torch.Tensor:
-    """[Cout,Cin,3,3] float32 device tensor -> packed float16 filter bank for conv3x3_f16."""
+def pack_conv3x3_f16(weight: torch.Tensor, split: bool = False) -> torch.Tensor:
+    """[Cout,Cin,3,3] float32 device tensor -> packed float16 filter bank for conv3x3_f16.
+    split (Cout <= 16): the unused half of the 32-row cout tile carries each filter's rounding residual, i.e. ~22-bit
+    filters at the same MFMA cost -- pass split_w=True to conv3x3_f16 (the 2-channel flow heads use it)."""
     _require_device(weight, "weight")
     if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
         raise ValueError("expected float32 [Cout,Cin,3,3], got %s %s" % (weight.dtype, tuple(weight.shape)))
     lib = _lib.load()
     cout, cin = weight.shape[:2]
+    if split and cout > 16:
+        raise ValueError("split filters need Cout <= 16, got %d" % cout)
     nbytes = lib.pwc_conv3x3_f16_packed_bytes(cin, cout)
     wp = torch.empty((nbytes // 2,), dtype=torch.float16, device=weight.device)
+    fn = lib.pwc_conv3x3_f16_pack_split if split else lib.pwc_conv3x3_f16_pack
     with torch.cuda.device(weight.device):
-        rc = lib.pwc_conv3x3_f16_pack(weight.contiguous().data_ptr(), wp.data_ptr(), cin, cout, _stream(weight))
-    check(rc, "pwc_conv3x3_f16_pack")
+        rc = fn(weight.contiguous().data_ptr(), wp.data_ptr(), cin, cout, _stream(weight))
+    check(rc, "pwc_conv3x3_f16_pack_split" if split else "pwc_conv3x3_f16_pack")
     return wp
 
 
 def conv3x3_f16(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cin: int, cout: int, stride: int = 1,
-                dilation: int = 1, leaky_slope: Optional[float] = 0.1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """3x3 convolution (padding = dilation) + bias (+ LeakyReLU) on c8 float16 activations, fp32 accumulation."""
+                dilation: int = 1, leaky_slope: Optional[float] = 0.1, out: Optional[torch.Tensor] = None,
+                out_f32: bool = False, split_w: bool = False) -> torch.Tensor:
+    """3x3 convolution (padding = dilation) + bias (+ LeakyReLU) on c8 float16 activations, fp32 accumulation.
+    out_f32: the result stays float32 (c8 layout) instead of being rounded to half; split_w: `wpacked` comes from
+    pack_conv3x3_f16(split=True)."""
     lib = _lib.load()
     bsx = _c8_bstride(x, "x")
     B, cg, H, W, _ = x.shape
     if cg != (cin + 7) // 8:
         raise ValueError("x has %d channel groups, Cin=%d needs %d" % (cg, cin, (cin + 7) // 8))
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    odt = torch.float32 if out_f32 else torch.float16
     if out is None:
-        out = torch.empty(c8_shape(B, cout, ho, wo), dtype=torch.float16, device=x.device)
+        out = torch.empty(c8_shape(B, cout, ho, wo), dtype=odt, device=x.device)
     elif tuple(out.shape) != c8_shape(B, cout, ho, wo):
         raise ValueError("out must be %s" % (c8_shape(B, cout, ho, wo),))
-    bsy = _c8_bstride(out, "out")
+    bsy = _c8_bstride(out, "out", odt)
+    if split_w and cout > 16:
+        raise ValueError("split filters need Cout <= 16, got %d" % cout)
     need = lib.pwc_conv3x3_f16_packed_bytes(cin, cout)
     if wpacked.dtype != torch.float16 or wpacked.numel() * 2 != need or wpacked.device != x.device:
         raise ValueError("packed filters do not match Cin=%d Cout=%d" % (cin, cout))
@@ -105,7 +116,8 @@ def conv3x3_f16(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cin:
         raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
     with torch.cuda.device(x.device):
         rc = lib.pwc_conv2d_f16_fwd(x.data_ptr(), wpacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout,
-                                    stride, dilation, FLAG_ACT_LEAKY if leaky_slope is not None else 0,
+                                    stride, dilation, (FLAG_ACT_LEAKY if leaky_slope is not None else 0) |
+                                    (_lib.FLAG_CONV_OUT_F32 if out_f32 else 0) | (_lib.FLAG_CONV_SPLIT_W if split_w else 0),
                                     float(leaky_slope or 0.0), bsx, bsy, _stream(x))
     check(rc, "pwc_conv2d_f16_fwd")
     return out
@@ -152,23 +164,32 @@ def warp_c8(x: torch.Tensor, flo: torch.Tensor, channels: int, flo_channel: int 
     return out
 
 
-def level_entry(c1: torch.Tensor, c2: torch.Tensor, flow_phases: torch.Tensor, feat_phases: torch.Tensor, channels: int,
+def level_entry(c1: torch.Tensor, c2: torch.Tensor, flow32: torch.Tensor, feat_phases: torch.Tensor,
+                deconv_w: torch.Tensor, deconv_b: torch.Tensor, channels: int,
                 c1_dst: torch.Tensor, flow_group: torch.Tensor, out: torch.Tensor, flow_scale: float = 1.0,
                 align_corners: bool = False, mask_threshold: float = 0.9999) -> torch.Tensor:
-    """Entry of a decoder level in one launch (PWCNet.py:208-212): pixel-shuffle the 4-phase transposed-conv outputs
-    `flow_phases` / `feat_phases` [B,1,H/2,W/2,8] into channels 0..3 of `flow_group` [B,1,H,W,8], copy c1 into
-    `c1_dst`, and write warp(c2, up_flow * flow_scale) to `out`."""
+    """Entry of a decoder level in one launch (PWCNet.py:208-212): up_flow = deconvL(flow) computed in fp32 from
+    `flow32` (float32 c8 [B,1,H/2,W/2,8], flow in channels 0,1) with the ConvTranspose2d parameters `deconv_w`
+    [2,2,4,4] / `deconv_b` [2]; up_feat from the 4-phase float32 tensor `feat_phases` [B,1,H/2,W/2,8]; both rounded to
+    half into channels 0..3 of `flow_group` [B,1,H,W,8]; c1 copied into `c1_dst`; warp(c2, up_flow * flow_scale)
+    (fp32 up_flow) written to `out`."""
     lib = _lib.load()
     B, cg, H, W, _ = c2.shape
     if cg != (channels + 7) // 8 or c1.shape != c2.shape or c1_dst.shape != c2.shape or out.shape != c2.shape:
         raise ValueError("c1, c2, c1_dst, out must all be [B,%d,H,W,8]" % ((channels + 7) // 8))
-    if H % 2 or W % 2 or tuple(flow_phases.shape) != (B, 1, H // 2, W // 2, 8) or feat_phases.shape != flow_phases.shape \
+    if H % 2 or W % 2 or tuple(flow32.shape) != (B, 1, H // 2, W // 2, 8) or feat_phases.shape != flow32.shape \
             or tuple(flow_group.shape) != (B, 1, H, W, 8):
-        raise ValueError("phase tensors must be [B,1,H/2,W/2,8] and flow_group [B,1,H,W,8]")
-    strides = [_c8_bstride(t, n) for t, n in ((c1, "c1"), (c2, "c2"), (flow_phases, "flow_phases"), (feat_phases, "feat_phases"),
-                                              (c1_dst, "c1_dst"), (flow_group, "flow_group"), (out, "out"))]
+        raise ValueError("flow32 / feat_phases must be [B,1,H/2,W/2,8] and flow_group [B,1,H,W,8]")
+    for t, n, shp in ((deconv_w, "deconv_w", (2, 2, 4, 4)), (deconv_b, "deconv_b", (2,))):
+        if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous() or t.device != c2.device:
+            raise ValueError("%s must be contiguous float32 %s on %s" % (n, shp, c2.device))
+    strides = [_c8_bstride(t, n, dt) for t, n, dt in (
+        (c1, "c1", torch.float16), (c2, "c2", torch.float16), (flow32, "flow32", torch.float32),
+        (feat_phases, "feat_phases", torch.float32), (c1_dst, "c1_dst", torch.float16),
+        (flow_group, "flow_group", torch.float16), (out, "out", torch.float16))]
     with torch.cuda.device(c2.device):
-        rc = lib.pwc_level_entry_c8_f16(c1.data_ptr(), c2.data_ptr(), flow_phases.data_ptr(), feat_phases.data_ptr(),
+        rc = lib.pwc_level_entry_c8_f16(c1.data_ptr(), c2.data_ptr(), flow32.data_ptr(), feat_phases.data_ptr(),
+                                        deconv_w.data_ptr(), deconv_b.data_ptr(),
                                         c1_dst.data_ptr(), flow_group.data_ptr(), out.data_ptr(), B, channels, H, W,
                                         float(flow_scale), 1 if align_corners else 0, float(mask_threshold),
                                         *strides, _stream(c2))

@@ -1,0 +1,134 @@
+"""Dev script (not a test): CPU emulation of the half-precision plan's roundings on top of the oracle's forward, to
+find which stored tensors carry the EPE of the fp16 path.  Every conv accumulates in fp64 here, so
+the only error sources are the roundings switched on below.
+
+    python tests/f16_error_budget.py [s|m|full|kitti]
+
+Switches (all True = the round-1 plan):
+  w      filters rounded to half                         act    conv outputs (trunk activations) rounded to half
+  corr   cost volume rounded to half                     warp   warped features rounded to half
+  head   predict_flow outputs rounded to half            upflow deconv output (up_flow) rounded to half before the warp
+  flowin up_flow/up_feat rounded to half as conv inputs  headw  head / deconv filters rounded to half
+"""
+import os
+import re
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pwc_oracle as O                                   # noqa: E402
+from opticalflow_amd.weights import synthetic_state_dict             # noqa: E402
+
+
+def q(x):
+    return x.half().to(x.dtype)
+
+
+def forward(sd, x, cfg, all_levels=False):
+    dt = torch.float64
+    x = x.to(dt)
+
+    def qif(flag, t):
+        return q(t) if cfg[flag] else t
+
+    groups = cfg.get("groups")
+
+    def group_of(name):
+        if name.startswith("dc_"):
+            return "ctx"
+        m = re.match(r"conv(\d)_", name)
+        return "dec" + m.group(1) if m else "pyr"
+
+    def conv(name, t, stride=1, dilation=1, act=True, wflag="w", oflag="act", first=False):
+        key = name + ".0" if (name + ".0.weight") in sd else name
+        w = sd[key + ".weight"].to(dt)
+        if groups is not None and wflag == "w" and group_of(name) not in groups:
+            wflag = oflag = "nop"
+        if not first:
+            w = qif(wflag, w)
+        y = F.conv2d(t, w, sd[key + ".bias"].to(dt), stride=stride, padding=dilation, dilation=dilation)
+        if act:
+            y = O.leaky_relu(y)
+        return qif(oflag, y)
+
+    def deconv(name, t, wflag, oflag):
+        w = qif(wflag, sd[name + ".weight"].to(dt))
+        return qif(oflag, F.conv_transpose2d(t, w, sd[name + ".bias"].to(dt), stride=2, padding=1))
+
+    feats = []
+    for im in (x[:, :3], x[:, 3:]):
+        pyr, t = [], im
+        for i, (name, stride) in enumerate(O.PYRAMID):
+            t = conv(name, t, stride=stride, first=(i == 0))
+            if i % 3 == 2:
+                pyr.append(t)
+        feats.append(pyr)
+    flows = {}
+    up_flow = up_feat = None
+    for lvl in (6, 5, 4, 3, 2):
+        c1, c2 = feats[0][lvl - 1], feats[1][lvl - 1]
+        if lvl == 6:
+            xcat = qif("corr", O.leaky_relu(O.correlation(c1, c2, 4, 1, 4, 1, 1, 1)))
+        else:
+            wf = qif("upflow", up_flow)
+            w = qif("warp", O.warp(c2, wf * O.WARP_SCALE[lvl]))
+            corr = qif("corr", O.leaky_relu(O.correlation(c1, w, 4, 1, 4, 1, 1, 1)))
+            xcat = torch.cat((corr, c1, qif("flowin", up_flow), qif("flowin", up_feat)), 1)
+        for i in range(5):
+            xcat = torch.cat((conv("conv%d_%d" % (lvl, i), xcat), xcat), 1)
+        flow = conv("predict_flow%d" % lvl, xcat, act=False, wflag="headw", oflag="head")
+        flows[lvl] = flow
+        if lvl > 2:
+            up_flow = deconv("deconv%d" % lvl, flow, "headw", "nop")
+            up_feat = deconv("upfeat%d" % lvl, xcat, "headw", "nop")
+    t = xcat
+    for i, dil in enumerate(O.DILATIONS):
+        t = conv("dc_conv%d" % (i + 1), t, dilation=dil)
+    flow2 = flows[2] + conv("dc_conv7", t, act=False, wflag="headw", oflag="head")
+    if all_levels:
+        return flow2, flows[3], flows[4], flows[5], flows[6]
+    return flow2
+
+
+ALL = ("w", "act", "corr", "warp", "head", "upflow", "flowin", "headw")
+
+
+def cfg_of(on):
+    c = {k: (k in on) for k in ALL}
+    c["nop"] = False
+    return c
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "s"
+    shape, seed = {"s": ((1, 6, 64, 64), 1234), "m": ((2, 6, 128, 192), 1235), "full": ((1, 6, 448, 1024), 1234),
+                   "kitti": ((1, 6, 384, 1280), 77)}[which]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(shape, generator=g, dtype=torch.float32)
+    sd = synthetic_state_dict(O.state_dict_manifest(), seed=0, gain=0.85, bias_std=0.02)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = forward(sd, x, cfg_of(()), all_levels=True)
+        print("mean|flow2| %.3f" % ref[0].abs().mean().item())
+        runs = [("round-1 plan (everything half)", ALL),
+                ("only w", ("w",)), ("only act", ("act",)), ("only corr", ("corr",)), ("only warp", ("warp",)),
+                ("only head", ("head",)), ("only upflow", ("upflow",)), ("only flowin", ("flowin",)), ("only headw", ("headw",)),
+                ("fp32 flow chain (head, upflow, headw off)", ("w", "act", "corr", "warp", "flowin")),
+                ("... + warp off (fused into corr)", ("w", "act", "corr", "flowin")),
+                ("... + corr off", ("w", "act", "flowin")),
+                ("w + act only", ("w", "act"))]
+        if len(sys.argv) > 2 and sys.argv[2] == "groups":
+            runs = [("w+act in %s only" % g, ("w", "act", g)) for g in ("pyr", "dec6", "dec5", "dec4", "dec3", "dec2", "ctx")]
+        for name, on in runs:
+            c = cfg_of(on)
+            if len(on) == 3 and on[2] in ("pyr", "dec6", "dec5", "dec4", "dec3", "dec2", "ctx"):
+                c["groups"] = (on[2],)
+            out = forward(sd, x, c, all_levels=True)
+            print("%-50s EPE flow2 %.3e | " % (name, O.epe(out[0], ref[0])) +
+                  " ".join("L%d %.2e" % (l, O.epe(o, r)) for l, o, r in zip((3, 4, 5, 6), out[1:], ref[1:])), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@ Tolerance: the kernel accumulates in fp32 and rounds the result to half once, so
 """
 import pytest
 import torch
+import numpy as np
 import torch.nn.functional as F
 
 from conftest import seeded_rand
@@ -152,48 +153,127 @@ def test_warp_c8_vs_oracle(dev, align, thr):
 
 
 @pytest.mark.parametrize("B,C,H,W", [(2, 21, 14, 34), (1, 32, 8, 6), (3, 128, 28, 64)])
-def test_level_entry_equals_shuffle_copy_warp(dev, B, C, H, W):
-    """pwc_level_entry_c8_f16 (one launch) == pixel shuffle of both 4-phase tensors + c1 copy + pwc_warp_c8_f16, bit for bit;
-    operands are batch-strided slices of larger buffers as in the plan's arena."""
+def test_level_entry_fp32_flow_chain(dev, B, C, H, W):
+    """pwc_level_entry_c8_f16 (one launch): deconvL applied in fp32 to the fp32 flow of the level above, pixel shuffle of
+    the fp32 upfeat phases, c1 copy, warp with the fp32 up_flow.  Checked against torch's conv_transpose2d (fp64) and the
+    CPU oracle's warp; operands are batch-strided slices of larger buffers as in the plan's arena."""
     from opticalflow_amd import ops_f16 as F16
-    from opticalflow_amd.engine_f16 import PwcPlanF16
+    from oracle import pwc_oracle as O
     g = (C + 7) // 8
-    c1 = F16.to_c8(seeded_rand((B, C, H, W), 560, -1, 1).to(dev))
-    c2 = F16.to_c8(seeded_rand((B, C, H, W), 561, -1, 1).to(dev))
-    heads = (seeded_rand((B, 2, H // 2, W // 2, 8), 562, -3, 3).half().to(dev))    # group 1 = upfeat phases (head[l][:, 1:2])
-    flowp = (seeded_rand((B, 1, H // 2, W // 2, 8), 563, -3, 3).half().to(dev))    # deconv phases (upflow[l])
-    def fresh():
-        arena = torch.full((B, 3 + g + 1, H, W, 8), 0.25, dtype=torch.float16, device=dev)
-        arena[:, 3 + g] = 0
-        return arena, torch.zeros_like(c2)
-    a_ref, w_ref = fresh()
-    a_ref[:, 3:3 + g].copy_(c1)
-    fg = a_ref[:, 3 + g]
-    PwcPlanF16._shuffle(flowp[:, 0], fg[..., 0:2])
-    PwcPlanF16._shuffle(heads[:, 1], fg[..., 2:4])
-    F16.warp_c8(c2, a_ref[:, 3 + g:4 + g], C, flo_channel=0, flow_scale=1.25, out=w_ref)
-    a_got, w_got = fresh()
-    F16.level_entry(c1, c2, flowp, heads[:, 1:2], C, c1_dst=a_got[:, 3:3 + g], flow_group=a_got[:, 3 + g:4 + g], out=w_got,
-                    flow_scale=1.25)
+    c1f = seeded_rand((B, C, H, W), 560, -1, 1).half().float()
+    c2f = seeded_rand((B, C, H, W), 561, -1, 1).half().float()
+    c1, c2 = F16.to_c8(c1f.to(dev)), F16.to_c8(c2f.to(dev))
+    flow = seeded_rand((B, 2, H // 2, W // 2), 562, -3, 3)                           # fp32 flow of the level above
+    featp = seeded_rand((B, H // 2, W // 2, 8), 563, -3, 3)                          # upfeat phases, channel co*4 + py*2 + px
+    dw = seeded_rand((2, 2, 4, 4), 564, -0.5, 0.5)
+    db = seeded_rand((2,), 565, -0.1, 0.1)
+    head = torch.zeros(B, 2, H // 2, W // 2, 8)
+    head[:, 0, :, :, 0:2] = flow.permute(0, 2, 3, 1)
+    head[:, 0, :, :, 2:] = 99.0                                                       # must be ignored
+    head[:, 1] = featp
+    head = head.to(dev)
+    arena = torch.full((B, 3 + g + 1, H, W, 8), 0.25, dtype=torch.float16, device=dev)
+    arena[:, 3 + g] = 0
+    warped = torch.zeros_like(c2)
+    F16.level_entry(c1, c2, head[:, 0:1], head[:, 1:2], dw.to(dev), db.to(dev), C, c1_dst=arena[:, 3:3 + g],
+                    flow_group=arena[:, 3 + g:4 + g], out=warped, flow_scale=1.25)
     torch.cuda.synchronize()
-    assert torch.equal(a_got, a_ref) and torch.equal(w_got, w_ref)
-    assert (a_got[:, :3] == 0.25).all() and (a_got[:, 3 + g, ..., 4:] == 0).all()
+    up = F.conv_transpose2d(flow.double(), dw.double(), db.double(), stride=2, padding=1)          # [B,2,H,W]
+    fg = arena[:, 3 + g].cpu().float()                                                               # [B,H,W,8]
+    assert (fg[..., 0:2] - up.permute(0, 2, 3, 1).float()).abs().max().item() <= 2e-3 * max(1.0, up.abs().max().item())
+    feat = featp.view(B, H // 2, W // 2, 2, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, H, W, 2)      # [b, 2y+py, 2x+px, co]
+    assert torch.equal(fg[..., 2:4], feat.half().float())
+    assert (fg[..., 4:] == 0).all() and (arena[:, :3] == 0.25).all()
+    assert torch.equal(arena[:, 3:3 + g], c1)
+    ref = O.warp(c2f, up.float() * 1.25)
+    got = F16.from_c8(warped, C).cpu()
+    assert ((got == 0) == (ref == 0)).float().mean().item() > 0.995                                 # mask decisions
+    assert (got - ref).abs().max().item() < 2e-3
     with pytest.raises(Exception):
-        F16.level_entry(c1[:, :, :H - 1], c2[:, :, :H - 1], flowp, heads[:, 1:2], C, c1_dst=a_got[:, 3:3 + g, :H - 1],
-                        flow_group=a_got[:, 3 + g:4 + g, :H - 1], out=w_got[:, :, :H - 1])
+        F16.level_entry(c1[:, :, :H - 1], c2[:, :, :H - 1], head[:, 0:1], head[:, 1:2], dw.to(dev), db.to(dev), C,
+                        c1_dst=arena[:, 3:3 + g, :H - 1], flow_group=arena[:, 3 + g:4 + g, :H - 1], out=warped[:, :, :H - 1])
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(565, 2, 16, 40), (533, 16, 9, 33), (32, 2, 24, 64)])
+def test_conv3x3_f16_split_filters_fp32_out(dev, cin, cout, H, W):
+    """Flow heads: split filters (hi + residual/2^11 in the idle half of the 32-row cout tile) and float32 output.
+    Against torch fp64 on the UNROUNDED float32 filters the error must be far below the half-filter kernel's."""
+    from opticalflow_amd import ops_f16 as F16
+    x = seeded_rand((2, cin, H, W), 570, -1, 1).half().float()
+    w = seeded_rand((cout, cin, 3, 3), 571, -1, 1) * (2.0 / (cin * 9)) ** 0.5
+    bias = seeded_rand((cout,), 572, -0.5, 0.5)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    xc = F16.to_c8(x.to(dev))
+    y32 = F16.conv3x3_f16(xc, F16.pack_conv3x3_f16(w.to(dev), split=True), bias.to(dev), cin, cout, leaky_slope=None,
+                          out_f32=True, split_w=True)
+    assert y32.dtype == torch.float32 and y32.shape == (2, (cout + 7) // 8, H, W, 8)
+    got = y32.permute(0, 1, 4, 2, 3).reshape(2, -1, H, W)[:, :cout].cpu().double()
+    err_split = (got - ref).abs().max().item()
+    y16 = F16.conv3x3_f16(xc, F16.pack_conv3x3_f16(w.to(dev)), bias.to(dev), cin, cout, leaky_slope=None)
+    err_half = (F16.from_c8(y16, cout).cpu().double() - ref).abs().max().item()
+    print("split+fp32 err %.2e, half filters + half out err %.2e" % (err_split, err_half))
+    assert err_split <= 2e-5 * max(1.0, ref.abs().max().item()) and err_split < 0.1 * err_half
+    if cout % 8:
+        assert (y32[:, -1, :, :, cout % 8:] == 0).all()
+    with pytest.raises(ValueError):
+        F16.pack_conv3x3_f16(seeded_rand((32, 8, 3, 3), 1).to(dev), split=True)
+
+
+def test_half_stores_saturate_no_inf_nan(dev):
+    """SURVEY section 7 risk 2 / ADVICE r1: an un-normalised cost volume over C=196 channels of O(10..30) features exceeds the
+    half range.  Every store to half saturates at +-65504 (never inf, so no inf-inf = NaN downstream); values inside
+    the range keep the usual 1e-3 relative accuracy; the normalised mode (/C) stays in range."""
+    from opticalflow_amd import PWCDCNet, ops_f16 as F16
+    from opticalflow_amd.weights import synthetic_state_dict
+    from oracle import pwc_oracle as O
+    for shape in ((1, 196, 7, 16), (2, 196, 24, 64)):                     # direct kernel / LDS-tiled kernel
+        a = seeded_rand(shape, 580, -30, 30).half().float()
+        b = a.clone()                                                      # in1 == in2: the zero-displacement channel is sum a^2 ~ 58800..
+        b[:, :, ::2] *= 1.5
+        b = b.half().float()
+        ref = O.correlation(a, b, 4, 1, 4, 1, 1, 1)
+        assert ref.abs().max().item() > 65504
+        got = F16.from_c8(F16.correlation_c8(F16.to_c8(a.to(dev)), F16.to_c8(b.to(dev)), 196), 81).cpu()
+        assert torch.isfinite(got).all() and got.abs().max().item() == 65504.0
+        big = ref.abs() >= 65504
+        assert (got[big].abs() == 65504).all() and (torch.sign(got[big]) == torch.sign(ref[big])).all()
+        assert ((got - ref)[~big].abs() <= 1e-3 * ref[~big].abs() + 0.1).all()      # half rounding + fp32 accumulation of ~1e5-sized terms
+        gotn = F16.from_c8(F16.correlation_c8(F16.to_c8(a.to(dev)), F16.to_c8(b.to(dev)), 196, normalize=True), 81).cpu()
+        assert (gotn - ref / 196).abs().max().item() <= 1e-3 * (ref / 196).abs().max().item()
+    # conv: a layer whose outputs exceed the range
+    x = seeded_rand((1, 64, 12, 40), 581, 100, 200).half().float()
+    w = torch.full((32, 64, 3, 3), 1.0)
+    w[16:] = -1.0
+    y = F16.from_c8(F16.conv3x3_f16(F16.to_c8(x.to(dev)), F16.pack_conv3x3_f16(w.to(dev)), torch.zeros(32, device=dev), 64, 32,
+                                    leaky_slope=None), 32).cpu()
+    assert torch.isfinite(y).all() and (y[:, :16, 2:-2, 2:-2] == 65504).all() and (y[:, 16:, 2:-2, 2:-2] == -65504).all()
+    # whole network with exploding activations (gain 2.5 per layer instead of 0.85): finite output, no NaN
+    net = PWCDCNet(precision="fp16").to(dev).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=3, gain=2.5, bias_std=0.02))
+    out = net(seeded_rand((1, 6, 64, 128), 582).to(dev))
+    assert torch.isfinite(out).all()
+
+
+# Bars of the half-precision plan (fp32 flow chain, split head filters; see DESIGN.md section 7 and
+# profiles/r02_f16_error_budget.txt): the network stores ~25 tensors per level in half (11-bit significands), which
+# alone puts the flow ~1e-3 RELATIVE from the fp32 result -- a CPU emulation with nothing but those roundings gives
+# 0.6e-3 / 1.0e-3 / 1.4e-3 on the three inputs below (mean |flow| 0.61 / 0.92 / 1.34).
+# Measured on MI355X with the fp32 flow chain: 0.63e-3 / 1.11e-3 / 1.61e-3 (round 1, flow chain in half: 0.8 / 1.5 / 2.1).
+F16_EPE_BAR = {"s": 1.0e-3, "m": 1.3e-3, "full": 1.9e-3}          # absolute mean EPE, flow2 units
+F16_REL_BAR = 1.4e-3                                             # and relative to mean |flow|
 
 
 def test_forward_fp16_vs_reference_golden(dev):
-    """Whole network with half-precision activations/filters (fp32 accumulation) vs the reference's fp32 output on the
-    golden inputs.  Bar: mean EPE <= 1e-2 * mean |flow|; observed ~1e-3 relative."""
+    """Whole network with half-precision activations/filters (fp32 accumulation, fp32 flow chain) vs the reference's fp32
+    output on the golden inputs, and vs the CPU oracle at 1 x 448 x 1024 (BASELINE geometry)."""
     from conftest import load_golden
     from opticalflow_amd import PWCDCNet
     from opticalflow_amd.weights import synthetic_state_dict
     from oracle import pwc_oracle as O
     g = load_golden("g3_forward.npz")
     net = PWCDCNet(precision="fp16").to(dev).eval()
-    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=int(g["wseed"]), gain=float(g["gain"]),
-                                             bias_std=float(g["bias_std"])))
+    sd = synthetic_state_dict(net.manifest(), seed=int(g["wseed"]), gain=float(g["gain"]), bias_std=float(g["bias_std"]))
+    net.load_state_dict(sd)
     for tag in ("s", "m"):
         x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag]).to(dev)
         f2 = net(x).cpu()
@@ -201,7 +281,7 @@ def test_forward_fp16_vs_reference_golden(dev):
         assert f2.shape == ref.shape and f2.dtype == torch.float32
         epe, scale = O.epe(f2, ref), ref.abs().mean().item()
         print("fp16 forward [%s]: EPE %.3e, mean|flow| %.3f" % (tag, epe, scale))
-        assert epe <= 1e-2 * scale, (tag, epe, scale)
+        assert epe < F16_EPE_BAR[tag] and epe < F16_REL_BAR * scale, (tag, epe, scale)
     eager = net(x)
     net.use_graph = True
     assert torch.equal(net(x), eager) and torch.equal(net(x), eager)
@@ -210,7 +290,19 @@ def test_forward_fp16_vs_reference_golden(dev):
     assert len(outs) == 5 and all(o.dtype == torch.float32 for o in outs)
     for lvl, o in zip((2, 3, 4, 5, 6), outs):
         ref_l = torch.from_numpy(g["train_flow%d_m" % lvl])
-        assert o.shape == ref_l.shape and O.epe(o.cpu(), ref_l) <= 1e-2 * max(ref_l.abs().mean().item(), 1e-2), lvl
+        e = O.epe(o.cpu(), ref_l)
+        print("fp16 forward [m] flow%d: EPE %.3e, mean|flow| %.3f" % (lvl, e, ref_l.abs().mean().item()))
+        assert o.shape == ref_l.shape and e <= 2e-3 * max(ref_l.abs().mean().item(), 1e-1), lvl
+    net.eval()
+    # BASELINE geometry, one pair, against the CPU oracle (fp32) run here
+    xf = torch.rand(1, 6, 448, 1024, generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        ref = O.pwc_forward(sd, xf)
+    net.use_graph = False
+    f2 = net(xf.to(dev)).cpu()
+    epe, scale = O.epe(f2, ref), ref.abs().mean().item()
+    print("fp16 forward [1x448x1024]: EPE %.3e, mean|flow| %.3f" % (epe, scale))
+    assert epe < F16_EPE_BAR["full"] and epe < F16_REL_BAR * scale
     with pytest.raises(ValueError):
         PWCDCNet(precision="bf16")
 
@@ -251,7 +343,7 @@ def test_forward_fp16_old_variant(dev):
         p16, p32 = net16._plan_for(x), net32._plan_for(x)
         for l in (6, 5, 4, 3):
             a = p32.flow[l]
-            b = p16.head[l][:, 0, :, :, 0:2].permute(0, 3, 1, 2).float()
+            b = p16.head[l][:, 0, :, :, 0:2].permute(0, 3, 1, 2)
             assert (a - b).abs().max().item() <= 1e-2 * max(a.abs().max().item(), 1e-3), (tag, l)
         ref = torch.from_numpy(g["flow2_" + tag])
         assert O.epe(f32, ref) < 1e-3
@@ -263,7 +355,7 @@ def test_forward_fp16_old_variant(dev):
 def test_forward_fp16_full_size_batch16_repeatable(dev):
     """BASELINE geometry (16 x 6 x 448 x 1024): the half-precision plan is bit-reproducible run to run (fixed reduction
     orders, no atomics; exercises the 16-row tiles, 2-slot rings and two-per-CU variants the small cases do not reach) and
-    stays within 1e-2 x mean|flow| of the fp32 plan of the same model."""
+    stays within F16_REL_BAR x mean|flow| (+35 % for the batch's worst items) of the fp32 plan of the same model."""
     from opticalflow_amd import PWCDCNet
     from opticalflow_amd.weights import synthetic_state_dict
     from oracle import pwc_oracle as O
@@ -279,4 +371,4 @@ def test_forward_fp16_full_size_batch16_repeatable(dev):
     ref = net32(x)
     epe, scale = O.epe(a.cpu(), ref.cpu()), ref.abs().mean().item()
     print("fp16 vs fp32 plan at 16x448x1024: EPE %.3e, mean|flow| %.3f" % (epe, scale))
-    assert torch.isfinite(a).all() and epe <= 1e-2 * scale
+    assert torch.isfinite(a).all() and epe <= 1.35 * F16_REL_BAR * scale

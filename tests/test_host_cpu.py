@@ -42,10 +42,13 @@ def test_abi_argument_errors_without_gpu():
     assert lib.pwc_conv3x3_packed_bytes(0, 2, 0) == -1
     assert lib.pwc_conv3x3_packed_bytes(8, 8, 1) == -1          # f16 weights not supported
     # decoder level entry: the level must be exactly twice the level above (PWCNet.py:208-212 needs even H, W)
-    fake = [ctypes.c_void_p(4096)] * 7
+    fake = [ctypes.c_void_p(4096)] * 9
     assert lib.pwc_level_entry_c8_f16(*fake, 1, 32, 7, 16, 1.25, 0, 0.9999, *([8] * 7), None) == -1
     assert b"even" in lib.pwc_last_error()
     assert lib.pwc_level_entry_c8_f16(None, *fake[1:], 1, 32, 8, 16, 1.25, 0, 0.9999, *([8] * 7), None) == -1
+    # split filters (flow heads) exist for Cout <= 16 only
+    assert lib.pwc_conv3x3_f16_pack_split(ctypes.c_void_p(4096), ctypes.c_void_p(4096), 64, 32, None) == -2
+    assert lib.pwc_conv2d_f16_fwd(*([ctypes.c_void_p(4096)] * 4), 1, 64, 8, 8, 32, 1, 1, 16, 0.0, 4096, 4096, None) == -2
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -169,3 +169,51 @@ def test_batched_graphed_infer_equals_eager(gpu_device):
     got = torch.cat(outs, 0)
     # the batch-2 plan may pick other conv tiles than the batch-1 plan (fp32 summation order): 1e-5 relative
     assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_kitti_fp16_full_size_stream(gpu_device):
+    """BASELINE configs[4] on its own workload: 375 x 1242 uint8 pairs from host memory -> double-buffered upload ->
+    GraphedInfer(precision='fp16') = normalise + replicate-pad to 384 x 1280 + half-precision forward + unpad + resize as
+    one HIP graph.  One pair against the CPU oracle run through the same pre/post-processing; then a batch: the
+    4-pairs-per-replay pipeline against the pair-by-pair one, bit-repeatability, finiteness, output geometry."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    H, W = 375, 1242
+    net = PWCDCNet(precision="fp16").to(gpu_device).eval()
+    sd = synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(21)
+    # smooth-ish synthetic frames (a random low-resolution image upsampled, second frame shifted) + noise, as uint8
+    def frame_pair():
+        base = torch.rand(1, 3, 24, 78, generator=g)
+        big = F.interpolate(base, size=(H + 16, W + 16), mode="bicubic", align_corners=False).clamp(0, 1)
+        a = big[0, :, 8:8 + H, 8:8 + W]
+        b = big[0, :, 5:5 + H, 12:12 + W]
+        n = torch.rand(2, 3, H, W, generator=g) * 0.08
+        return tuple(((t + n[i]).clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0).contiguous() for i, t in enumerate((a, b)))
+    samples = [frame_pair() for _ in range(5)]
+    pipe = kitti.GraphedInfer(net, H, W, gpu_device)
+    got = [pipe(u8).clone() for u8 in kitti.PairStream(samples, gpu_device, raw=True)]
+    assert all(o.shape == (1, 2, H, W) and o.dtype == torch.float32 and torch.isfinite(o).all() for o in got)
+    # one pair vs the oracle
+    a, b = kitti.normalize_pair(*samples[0])
+    x, ph, pw = kitti.pad_to_64(torch.cat([a, b], 1))
+    assert x.shape == (1, 6, 384, 1280) and (ph, pw) == (9, 38)
+    with torch.no_grad():
+        raw = O.pwc_forward(sd, x)
+        ref = kitti.flow_resize(kitti.unpad(raw, ph, pw), H, W)
+    epe, scale = O.epe(got[0].cpu(), ref), ref.abs().mean().item()
+    print("KITTI fp16 375x1242: EPE %.3e px at full resolution, mean|flow| %.3f (1/4-res network units: %.3e / %.3f)"
+          % (epe, scale, epe / (W / 282.0), raw.abs().mean().item()))
+    assert epe < 1.8e-3 * scale          # measured 1.46e-3 relative (fp16 rounding floor ~1e-3 relative, DESIGN.md section 7)
+    # repeatability: the same pairs again -> the same bits
+    again = [pipe(u8).clone() for u8 in kitti.PairStream(samples, gpu_device, raw=True)]
+    assert all(torch.equal(p, q) for p, q in zip(got, again))
+    # 4 pairs per replay (ragged tail of 1) vs pair by pair: other conv tiles may be picked -> fp16 rounding noise only
+    pipe4 = kitti.GraphedInfer(net, H, W, gpu_device, batch=4)
+    outs = [pipe4(u8).clone() for u8 in kitti.BatchStream(samples, gpu_device, 4)]
+    assert [o.shape[0] for o in outs] == [4, 1]
+    got4 = torch.cat(outs, 0)
+    ref1 = torch.cat(got, 0)
+    assert O.epe(got4.cpu(), ref1.cpu()) < 1.8e-3 * ref1.abs().mean().item()
