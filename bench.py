@@ -81,67 +81,105 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PWC_BENCH_CPU_THREADS", "16"))))
 
 
-def pmc_traffic(key, applies):
-    """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately and
-    corrected as the MI355X guide prescribes; see profiles/r01_pmc_traffic.json).  Counters cannot be read
-    live, so this is the committed measurement of the same kernel on the same workload, or None."""
+PMC_FILE = "r02_pmc_traffic.json"
+
+
+def pmc_record(key, applies):
+    """rocprofv3 evidence for a probed kernel, from the COMMITTED profile of the same kernel on the same workload
+    (profiles/r02_pmc_traffic.json, written by tools/install_profiles.py from separate --pmc / --kernel-trace passes;
+    counters cannot be read from inside this process).  Returns {"traffic", "traffic_source", "rocprof_avg_ms"} or {}."""
     if not applies:
-        return None
+        return {}
     try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
-            return int(json.load(f)[key]["traffic_bytes"])
+        with open(os.path.join(REPO, "profiles", PMC_FILE)) as f:
+            rec = json.load(f)[key]
+        out = {"traffic": int(rec["traffic_bytes"]), "traffic_source": "profiles/%s (%s)" % (PMC_FILE, rec.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE"))}
+        if "rocprof_avg_ms" in rec:
+            out["rocprof_avg_ms"] = float(rec["rocprof_avg_ms"])
+        return out
     except (OSError, KeyError, ValueError):
-        return None
+        return {}
 
 
-def event_time_ms(fn, reps, stream):
-    """Average duration of fn() over `reps` back-to-back launches, HIP events on the launch stream."""
+def event_time_ms(fns, reps, stream):
+    """Mean duration of one launch over `reps` back-to-back launches, HIP events on the launch stream.  `fns` is one
+    callable or a list that is cycled through (operand sets larger than the 256 MiB Infinity Cache in total, so that an
+    HBM-bound kernel cannot be served from it)."""
+    if callable(fns):
+        fns = [fns]
     start = torch.cuda.Event(enable_timing=True)
     stop = torch.cuda.Event(enable_timing=True)
-    fn()
+    for fn in fns:
+        fn()
     stream.synchronize()
     start.record(stream)
-    for _ in range(reps):
-        fn()
+    for i in range(reps):
+        fns[i % len(fns)]()
     stop.record(stream)
     stop.synchronize()
     return start.elapsed_time(stop) / reps
 
 
+def last_conv_kernel():
+    from opticalflow_amd import _lib
+    return _lib.load().pwc_last_conv_kernel().decode()
+
+
+PROBE_REPS = 30
+
+
 def probes_fp32(result, args, plan, B, H, W, h2, w2, stream):
-    """roofline / roofline_corr / roofline_warp of the fp32 plan: HIP-event averages of back-to-back launches."""
+    """roofline / roofline_corr / roofline_warp of the fp32 plan: HIP-event means over PROBE_REPS back-to-back launches.
+    The HBM-bound probes rotate over three operand sets (3 x 266 MB at batch 16 > the 256 MiB Infinity Cache)."""
     from opticalflow_amd import ops
     full = B == 16 and (H, W) == (448, 1024)
     if args.conv_backend == "hip":
         cin = plan.arena[2].shape[1]
         flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
-        ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
+        ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), PROBE_REPS, stream)
         ach = flops / (ms * 1e-3) / 1e12
-        result["roofline"] = {"kernel": "conv3x3_mfma_kernel<4, 1, 1, 1, 1, 0> = <MT,NT,stride,dilation,two-per-CU,split-K> "
-                                        "(dc_conv1 %d->128 @%dx%d, B=%d)" % (cin, w2, h2, B),
+        rec = pmc_record("conv3x3_mfma_dc_conv1_b16", full)
+        result["roofline"] = {"kernel": "%s = <MT,NT,stride,dilation,two-per-CU,split-K> (dc_conv1 %d->128 @%dx%d, B=%d)"
+                                        % (last_conv_kernel(), cin, w2, h2, B),
                               "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                              "traffic": pmc_traffic("conv3x3_mfma_dc_conv1_b16", full),
-                              "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
+                              "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": rec.get("traffic"),
+                              "traffic_source": rec.get("traffic_source"),
+                              "avg_launch_ms": round(ms, 4), "launches_timed": PROBE_REPS, "algorithmic_flop_per_launch": flops}
+        if "rocprof_avg_ms" in rec:
+            result["roofline"]["frac_rocprof"] = round(flops / (rec["rocprof_avg_ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
     c2 = 32
     off = 448 + 81
     ar = plan.arena[2]
+    # three operand sets laid out like the arena's (corr slot | c1) channels + a warped tensor each
+    sets = [(torch.empty((B, 81 + c2, h2, w2), device=ar.device), torch.empty((B, c2, h2, w2), device=ar.device)) for _ in range(3)]
+    for mini, wrp in sets:
+        mini[:, 81:].copy_(ar[:, off:off + c2])
+        wrp.copy_(plan.warped[2])
     bytes_corr = (2 * c2 + 81) * h2 * w2 * 4 * B
-    ms = event_time_ms(lambda: ops.correlation(ar[:, off:off + c2], plan.warped[2], 4, 1, 4, 1, 1, 1.0,
-                                               leaky_slope=0.1, out=ar[:, 448:529]), 20, stream)
+    ms = event_time_ms([(lambda m=m, w_=w_: ops.correlation(m[:, 81:], w_, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1, out=m[:, :81]))
+                        for m, w_ in sets], PROBE_REPS, stream)
     gbs = bytes_corr / (ms * 1e-3) / 1e9
-    result["roofline_corr"] = {"kernel": "corr81_dma_kernel (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena write)" % (w2, h2, B),
+    rec = pmc_record("corr81_level2_b16", full)
+    result["roofline_corr"] = {"kernel": "corr81_dma_kernel (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena-strided write; "
+                                         "3 operand sets in rotation)" % (w2, h2, B),
                                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
-                               "traffic": pmc_traffic("corr81_level2_b16", full),
-                               "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
+                               "traffic": rec.get("traffic"), "traffic_source": rec.get("traffic_source"),
+                               "avg_launch_ms": round(ms, 4), "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_corr}
+    if "rocprof_avg_ms" in rec:
+        result["roofline_corr"]["frac_rocprof"] = round(bytes_corr / (rec["rocprof_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if args.conv_backend != "hip":
         result["roofline"] = result["roofline_corr"]
     bytes_warp = (2 * c2 + 2) * h2 * w2 * 4 * B
-    ms = event_time_ms(lambda: ops.warp(plan.c2[2], ar[:, off + c2:off + c2 + 2], 5.0, False, out=plan.warped[2]), 20, stream)
-    result["roofline_warp"] = {"kernel": "warp_kernel<f32> (level 2)", "bound": "hbm",
+    srcs = [plan.c2[2].clone() for _ in range(3)]
+    flo = ar[:, off + c2:off + c2 + 2]
+    ms = event_time_ms([(lambda s_=s_, w_=w_: ops.warp(s_, flo, 5.0, False, out=w_)) for s_, (_, w_) in zip(srcs, sets)],
+                       PROBE_REPS, stream)
+    result["roofline_warp"] = {"kernel": "warp_kernel<f32> (level 2; 3 operand sets in rotation)", "bound": "hbm",
                                "achieved": round(bytes_warp / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4)}
+                               "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
+                               "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_warp}
+    del sets, srcs
 
 
 def probes_fp16(result, plan, B, H, W, h2, w2, stream):
@@ -149,48 +187,147 @@ def probes_fp16(result, plan, B, H, W, h2, w2, stream):
     channels of dc_conv1 (the arena carries 576 with its zero pad channels); bytes are halves."""
     from opticalflow_amd import ops_f16 as F16
     from opticalflow_amd.engine_f16 import BASE_G, CORR_G
+    full = B == 16 and (H, W) == (448, 1024)
     flops = 2.0 * 128 * 565 * 9 * h2 * w2 * B
-    ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), 10, stream)
+    ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), PROBE_REPS, stream)
     ach = flops / (ms * 1e-3) / 1e12
-    result["roofline"] = {"kernel": "conv3x3_f16_kernel<4, 1, 1, 3> = <MT,stride,dilation,ring> (dc_conv1 565->128 @%dx%d, B=%d, "
-                                    "v_mfma_f32_32x32x16_f16)" % (w2, h2, B),
+    rec = pmc_record("conv3x3_f16_dc_conv1_b16", full)
+    result["roofline"] = {"kernel": "%s = <MT,NT,stride,dilation,ring,-> (dc_conv1 565->128 @%dx%d, B=%d, v_mfma_f32_32x32x16_f16)"
+                                    % (last_conv_kernel(), w2, h2, B),
                           "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
-                          "traffic": pmc_traffic("conv3x3_f16_dc_conv1_b16", B == 16 and (H, W) == (448, 1024)),
-                          "avg_launch_ms": round(ms, 4), "algorithmic_flop_per_launch": flops}
+                          "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": rec.get("traffic"),
+                          "traffic_source": rec.get("traffic_source"),
+                          "avg_launch_ms": round(ms, 4), "launches_timed": PROBE_REPS, "algorithmic_flop_per_launch": flops}
+    if "rocprof_avg_ms" in rec:
+        result["roofline"]["frac_rocprof"] = round(flops / (rec["rocprof_avg_ms"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
     ar = plan.arena[2]
     f0 = BASE_G + CORR_G
     c2 = 32
+    # six operand sets (133 MB each in halves) so that the rotation exceeds the Infinity Cache
+    sets = [(torch.zeros((B, CORR_G + 4, h2, w2, 8), device=ar.device, dtype=torch.float16),
+             torch.zeros((B, 4, h2, w2, 8), device=ar.device, dtype=torch.float16)) for _ in range(6)]
+    for mini, wrp in sets:
+        mini[:, CORR_G:].copy_(ar[:, f0:f0 + 4])
+        wrp.copy_(plan.warped[2])
     bytes_corr = (2 * c2 + 81) * h2 * w2 * 2 * B
-    ms = event_time_ms(lambda: F16.correlation_c8(ar[:, f0:f0 + 4], plan.warped[2], c2, leaky_slope=0.1,
-                                                  out=ar[:, BASE_G:BASE_G + CORR_G]), 20, stream)
+    ms = event_time_ms([(lambda m=m, w_=w_: F16.correlation_c8(m[:, CORR_G:], w_, c2, leaky_slope=0.1, out=m[:, :CORR_G]))
+                        for m, w_ in sets], PROBE_REPS, stream)
     gbs = bytes_corr / (ms * 1e-3) / 1e9
-    result["roofline_corr"] = {"kernel": "corr81_c8_kernel (level 2: C=32 @%dx%d, B=%d, f16, fused LeakyReLU, arena write)" % (w2, h2, B),
+    result["roofline_corr"] = {"kernel": "corr81_c8_kernel (level 2: C=32 @%dx%d, B=%d, f16, fused LeakyReLU, arena-strided write; "
+                                         "6 operand sets in rotation)" % (w2, h2, B),
                                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
-                               "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": bytes_corr}
+                               "traffic": None, "avg_launch_ms": round(ms, 4), "launches_timed": PROBE_REPS,
+                               "algorithmic_bytes_per_launch": bytes_corr}
     bytes_warp = (2 * c2 + 2) * h2 * w2 * 2 * B
-    ms = event_time_ms(lambda: F16.warp_c8(plan.pyr_a[2][B:], ar[:, f0 + 4:f0 + 5], c2, flow_scale=5.0, out=plan.warped[2]), 20, stream)
-    result["roofline_warp"] = {"kernel": "warp_c8_kernel (level 2, f16)", "bound": "hbm",
+    srcs = [plan.pyr_a[2][B:].clone() for _ in range(6)]
+    ms = event_time_ms([(lambda s_=s_, w_=w_: F16.warp_c8(s_, ar[:, f0 + 4:f0 + 5], c2, flow_scale=5.0, out=w_))
+                        for s_, (_, w_) in zip(srcs, sets)], PROBE_REPS, stream)
+    result["roofline_warp"] = {"kernel": "warp_c8_kernel (level 2, f16; 6 operand sets in rotation)", "bound": "hbm",
                                "achieved": round(bytes_warp / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4)}
+                               "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
+                               "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_warp}
+    del sets, srcs
+
+
+def bench_kitti(args, rank, world, dev, rehearse):
+    """BASELINE configs[4]: KITTI-shaped stream (inference_kitti.py:227-266,296-314 loop) sharded over the ranks.  A step =
+    `batch` uint8 375x1242 pairs per rank taken from HOST memory: pinned double-buffered upload on a copy stream,
+    normalise + replicate-pad to 384x1280 + forward + unpad + resize as one HIP graph, gather of the quarter-resolution
+    flows to rank 0.  The PCIe upload is INSIDE the timed region (unlike the headline metric)."""
+    import torch.distributed as dist
+    from opticalflow_amd import PWCDCNet, kitti
+    from opticalflow_amd.parallel import broadcast_parameters
+    from opticalflow_amd.weights import synthetic_state_dict
+    H, W, B = 375, 1242, args.batch
+    net = PWCDCNet(precision=args.precision)
+    if rank == 0:
+        net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=GAIN, bias_std=BIAS_STD))
+    net = net.to(dev).eval()
+    bcast_bytes = broadcast_parameters(net, src=0) if world > 1 else 0
+    stream = kitti.ShardedStream.for_model(net, H, W, dev, batch=B)
+    g = torch.Generator().manual_seed(100 + rank)
+    pool = [(torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8),
+             torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)) for _ in range(2 * B)]
+
+    class Repeat:                                   # a stream of n pairs cycling over the pool (global index -> pool entry)
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return pool[(i // world) % len(pool)]
+
+    def run(steps):
+        last = None
+        for _, full, gathered in stream.run(Repeat(steps * B * world)):
+            last = gathered if rank == 0 else full
+        torch.cuda.synchronize()
+        return last
+
+    log("rank %d/%d: KITTI stream %dx%d %s, %d pairs per step and rank; warm-up x%d" % (rank, world, W, H, args.precision, B, args.warmup))
+    run(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = run(args.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        pairs = world * B * args.steps
+        ok = last is not None and bool(torch.isfinite(last[1]).all())
+        result = {
+            "metric": "image-pairs/sec KITTI 1242x375 stream %s (H2D included)" % args.precision, "value": round(pairs / elapsed, 3),
+            "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f16",
+            "data": "synthetic (uniform uint8 375x1242 pairs in host memory; seeded Kaiming-fan-in weights x0.85)",
+            "config": {"workload": "BASELINE configs[4]: KITTI 1242x375 stream (inference_kitti.py path), %s, per-GPU double-buffered "
+                                   "H2D, %d pairs per graph replay and rank" % (args.precision, B),
+                       "pairs_per_gpu": B, "global_batch": B * world, "height": H, "width": W, "padded": [384, 1280],
+                       "parallelism": "round-robin stream shard x%d (kitti.ShardedStream), weights broadcast %d B, quarter-resolution "
+                                      "flow gather to rank 0" % (world, bcast_bytes)},
+            "outputs_finite": ok,
+        }
+        if rehearse:
+            result["config"]["rehearsal"] = "all %d ranks on cuda:0 over gloo: plumbing check, NOT a measurement" % world
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="image pairs per GPU per step")
+    ap.add_argument("--steps", type=int, default=100)       # SURVEY section 8(d): >= 100 timed, >= 20 warm-up forwards
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default 16; 4 for --workload kitti)")
+    ap.add_argument("--workload", default="pairs", choices=["pairs", "kitti"],
+                    help="pairs = the headline metric (resident 1024x448 batch, BASELINE configs[2]/[3]); kitti = configs[4]: "
+                         "375x1242 uint8 pairs streamed from host memory through kitti.ShardedStream (H2D included)")
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--conv-backend", default="hip", choices=["hip", "torch"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "fp16"],
                     help="fp32 = the headline metric (BASELINE configs[2]); fp16 = half activations/filters, fp32 accumulation (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    if args.precision is None:
+        args.precision = "fp16" if args.workload == "kitti" else "fp32"
+    if args.batch is None:
+        args.batch = 4 if args.workload == "kitti" else 16
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,6 +358,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "kitti":
+        return bench_kitti(args, rank, world, dev, rehearse)
+
     B, H, W = args.batch, args.height, args.width
     net = PWCDCNet(conv_backend=args.conv_backend, use_graph=not args.no_graph, precision=args.precision)
     if rank == 0:
@@ -247,7 +387,7 @@ def main():
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize()
-        if rank == 0:
+        if rank == 0 and (i < 3 or i == args.warmup - 1):
             log("warm-up step %d done" % i)
     torch.cuda.synchronize()
     if world > 1:

@@ -60,6 +60,10 @@ extern "C" {
 
 int pwc_abi_version(void);
 const char *pwc_last_error(void);
+/* Name and template arguments of the MFMA convolution variant this thread launched last -- what the tile cost
+ * model picked for that layer: "conv3x3_mfma_kernel<MT, NT, stride, dilation, two-per-CU, 0>" (fp32) or
+ * "conv3x3_f16_kernel<MT, NT, stride, dilation, ring, 0>" (fp16).  For benchmarks and profiles. */
+const char *pwc_last_conv_kernel(void);
 
 /* Cost volume.  in1,in2: [B,C,H,W]; out: [B,(2*(max_disp/stride2)+1)^2,outH,outW] with
  * outH = ceil((H + 2*pad - 2*((k-1)/2 + max_disp)) / stride1)   (correlation_cuda.cc:25-38).

@@ -2,7 +2,7 @@
 the reference's Correlation / warp / PWCDCNet interface).  See DESIGN.md."""
 from ._lib import LIB_PATH, PwcHipError  # noqa: F401
 from .correlation import Correlation, CorrelationFunction  # noqa: F401
-from .pwcnet import PWCDCNet, pwc_dc_net  # noqa: F401
+from .pwcnet import PWCDCNet, PWCDCNet_old, pwc_dc_net, pwc_dc_net_old  # noqa: F401
 from .flowio import read_flo, write_flo  # noqa: F401
 
 __version__ = "0.1.0"

@@ -25,6 +25,7 @@ FLAG_CONV_SPLIT_W = 16
 SIGNATURES = {
     "pwc_abi_version": (c_int, []),
     "pwc_last_error": (c_char_p, []),
+    "pwc_last_conv_kernel": (c_char_p, []),
     "pwc_corr_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_float,
                              c_int64, c_int64, c_int64, c_void_p]),

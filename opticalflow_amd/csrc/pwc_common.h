@@ -13,6 +13,7 @@
 namespace pwc {
 
 void set_error(const char *fmt, ...);
+void note_kernel(const char *name, int a, int b, int c, int d, int e, int f);
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

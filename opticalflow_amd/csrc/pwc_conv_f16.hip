@@ -301,6 +301,7 @@ int launch16(const Args16 &a) {
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), smem, a.stream,
                            a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo, tiles_x, tiles_y,
                            a.bsx, a.bsy, a.slope, a.mode);
+        pwc::note_kernel("conv3x3_f16_kernel", MT, NT, S, D, R, 0);
         return pwc::check_launch("conv3x3_f16_kernel");
     }
 }

@@ -427,6 +427,7 @@ int launch(const ConvArgs &a) {
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
                            a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
                            tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky, 0, (int64_t)0);
+        pwc::note_kernel("conv3x3_mfma_kernel", MT, NT, S, D, TWO, 0);
         return pwc::check_launch("conv3x3_mfma_kernel");
     }
 }

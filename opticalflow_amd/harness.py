@@ -98,11 +98,14 @@ def main(argv=None) -> int:
     ap.add_argument("im2", nargs="?", default="data/frame_0011.png")
     ap.add_argument("out", nargs="?", default="./tmp/frame_0010.flo")
     ap.add_argument("--weights", default="./pwc_net.pth.tar")             # script_pwc.py:41
-    ap.add_argument("--trained-semantics", action="store_true",
-                    help="normalised correlation + align_corners=True (what published weights were trained with)")
+    ap.add_argument("--cpu-fallback-semantics", action="store_true",
+                    help="un-normalised correlation (the reference's USE_ONNX_CORRELATION fallback, this project's parity "
+                         "mode) instead of the native /C correlation that checkpoints are trained with")
+    ap.add_argument("--align-corners", action="store_true",
+                    help="warp with grid_sample(align_corners=True) (torch < 1.3 behaviour, what the published weights saw)")
     args = ap.parse_args(argv)
     from .pwcnet import pwc_dc_net
-    net = pwc_dc_net(args.weights, normalize_corr=args.trained_semantics, align_corners=args.trained_semantics)
+    net = pwc_dc_net(args.weights, normalize_corr=not args.cpu_fallback_semantics, align_corners=args.align_corners)
     net = net.cuda().eval()
     flo = estimate_flow(net, read_image(args.im1), read_image(args.im2))
     write_flo(args.out, flo.cpu())

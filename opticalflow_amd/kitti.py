@@ -278,7 +278,13 @@ class GraphedInfer:
 
     def _body(self) -> torch.Tensor:
         i1, i2 = normalize_pair(self.static_u8[:, 0], self.static_u8[:, 1])
-        return model_infer(self.model, i1, i2, self.reference_unpad)
+        h, w = i1.shape[-2:]
+        x, ph, pw = pad_to_64(torch.cat([i1, i2], dim=1))
+        out = self.model(x)
+        # the network's own output [batch,2,H_/4,W_/4] (a static buffer like `out`): what a sharded stream gathers
+        self.flow_quarter = out[0] if isinstance(out, (tuple, list)) else out
+        flow = unpad(self.flow_quarter, ph, pw) if self.reference_unpad else unpad(self.flow_quarter, ph // 4, pw // 4)
+        return flow_resize(flow, h, w)
 
     def __call__(self, pair_u8: torch.Tensor) -> torch.Tensor:
         """pair_u8: [2,H,W,3] (one pair) or [n,2,H,W,3] with n <= batch; returns the first n flows [n,2,H,W]."""
@@ -348,3 +354,124 @@ def evaluate_pairs(model, samples: Iterable[Tuple[torch.Tensor, torch.Tensor, np
     if not rows:
         return float("nan"), float("nan"), rows
     return float(np.nanmean([r[0] for r in rows])), float(np.nanmean([r[1] for r in rows])), rows
+
+
+# ------------------------------------------------------------------ the stream sharded over the GPUs of one node
+class HostBatcher:
+    """BatchStream without a device: yields [n,2,H,W,3] uint8 HOST batches (CPU rehearsal of ShardedStream under gloo)."""
+
+    def __init__(self, pairs, device, batch):
+        self.pairs, self.batch = iter(pairs), batch
+
+    def __iter__(self):
+        cur = []
+        for a, b in self.pairs:
+            cur.append(torch.stack((a[..., :3], b[..., :3])))
+            if len(cur) == self.batch:
+                yield torch.stack(cur)
+                cur = []
+        if cur:
+            yield torch.stack(cur)
+
+
+class ShardedStream:
+    """BASELINE configs[4]: the KITTI-shaped stream on the N GPUs of one node, one process per GPU.
+
+    The reference loop (inference_kitti.py:227-266,296-314) takes one pair at a time on one device.  Here rank r of N
+    takes pairs r, r+N, r+2N, ... of the stream (round robin: the ranks advance through the sequence together), each
+    rank with its OWN pinned double buffers and copy stream (BatchStream) and its own captured pipeline (GraphedInfer);
+    there is no communication inside a step.  Per step the quarter-resolution network outputs ([n,2,H_/4,W_/4],
+    245 KB per 375x1242 pair instead of 3.7 MB at full resolution) are gathered to rank 0 into buffers allocated once
+    (parallel.FlowGather); full-resolution flows stay on the rank that made them.
+
+    ``infer(u8 [n,2,H,W,3]) -> (flow_full [n,2,H,W], flow_quarter [n,2,h,w])`` and ``batcher`` default to the HIP pipeline;
+    the gloo test substitutes host stand-ins (the HIP forward needs a GPU)."""
+
+    def __init__(self, device, batch: int = 1, infer=None, batcher=None, group=None, gather: bool = True):
+        import torch.distributed as dist
+        self.device, self.batch, self.group, self.gather = device, batch, group, gather
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.infer = infer
+        self.batcher = batcher or BatchStream
+        self._gathers = {}
+
+    @classmethod
+    def for_model(cls, model, height: int, width: int, device, batch: int = 1, reference_unpad: bool = True, **kw):
+        pipe = GraphedInfer(model, height, width, device, reference_unpad=reference_unpad, batch=batch)
+
+        def infer(u8):
+            full = pipe(u8)
+            return full, pipe.flow_quarter[:u8.shape[0]]
+        return cls(device, batch=batch, infer=infer, **kw)
+
+    def my_indices(self, n_items: int):
+        return range(self.rank, n_items, self.world)
+
+    def step_counts(self, n_items: int):
+        """[steps][world] pairs each rank processes in each step (identical on every rank; rank 0 runs the most steps)."""
+        per_rank = [len(range(r, n_items, self.world)) for r in range(self.world)]
+        steps = -(-per_rank[0] // self.batch) if per_rank[0] else 0
+        return [[max(0, min(self.batch, c - s * self.batch)) for c in per_rank] for s in range(steps)]
+
+    def _gather(self, q: torch.Tensor, counts):
+        from .parallel import FlowGather
+        key = (tuple(counts), tuple(q.shape[1:]), q.dtype)
+        g = self._gathers.get(key)
+        if g is None:
+            g = self._gathers[key] = FlowGather(list(counts), tuple(q.shape[1:]), q.dtype, q.device, 0, self.group)
+        return g(q)
+
+    def run(self, pairs):
+        """pairs: a sequence of (img1_u8 [H,W,3], img2_u8) on the host.  Yields per step
+        (global indices of this rank's pairs, flow_full [n,2,H,W] or None, gathered): `gathered` is, on rank 0,
+        (global indices in rank-major order, quarter flows [sum n_r,2,h,w]); None elsewhere / when gather is off."""
+        n_items = len(pairs)
+        mine = list(self.my_indices(n_items))
+        plan = self.step_counts(n_items)
+        batches = iter(self.batcher((pairs[i] for i in mine), self.device, self.batch))
+        tail = None
+        for s, counts in enumerate(plan):
+            n = counts[self.rank]
+            idx = mine[s * self.batch:s * self.batch + n]
+            full = quarter = None
+            if n:
+                full, quarter = self.infer(next(batches))
+                tail = (tuple(quarter.shape[1:]), quarter.dtype, quarter.device)
+            gathered = None
+            if self.gather and self.world > 1:
+                if quarter is None:                      # a rank that ran out of pairs still joins the collective
+                    if tail is None:
+                        raise RuntimeError("rank %d has no pairs at all: use at most as many ranks as pairs" % self.rank)
+                    quarter = torch.zeros((0,) + tail[0], dtype=tail[1], device=tail[2])
+                flows = self._gather(quarter, counts)
+                if self.rank == 0:
+                    order = [r + self.world * (s * self.batch + k) for r in range(self.world) for k in range(counts[r])]
+                    gathered = (order, flows)
+            elif self.gather and n:
+                gathered = (idx, quarter)
+            yield idx, full, gathered
+
+
+def evaluate_pairs_sharded(stream: "ShardedStream", samples, group=None):
+    """inference_kitti.py:296-314 over a sharded stream: each rank scores the pairs it processed against their ground
+    truth (samples[i] = (img1_u8, img2_u8, flow_gt [H,W,2], valid [H,W])); only three numbers per rank travel:
+    (sum EPE, sum Fl-all, count).  Returns (mean EPE, mean Fl-all, n) on every rank."""
+    import torch.distributed as dist
+    acc = torch.zeros(3, dtype=torch.float64)
+    keep, stream.gather = stream.gather, False
+    try:
+        for idx, full, _ in stream.run([(s[0], s[1]) for s in samples]):
+            for k, i in enumerate(idx):
+                fp = full[k].permute(1, 2, 0).cpu().numpy()
+                e, f = epe_metric(fp, samples[i][2], samples[i][3]), fl_all_metric(fp, samples[i][2], samples[i][3])
+                if not (np.isnan(e) or np.isnan(f)):
+                    acc += torch.tensor([e, f, 1.0], dtype=torch.float64)
+    finally:
+        stream.gather = keep
+    if dist.is_initialized() and stream.world > 1:
+        wire = acc if dist.get_backend(group) == "gloo" else acc.to(stream.device)
+        dist.all_reduce(wire, group=group)
+        acc = wire.cpu()
+    n = int(acc[2].item())
+    return (float(acc[0] / n), float(acc[1] / n), n) if n else (float("nan"), float("nan"), 0)

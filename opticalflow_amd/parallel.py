@@ -47,35 +47,78 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> i
     return flat.numel() * flat.element_size()
 
 
+class FlowGather:
+    """Gather of per-rank flow fields [b_r, ...] to `dst` with every buffer allocated ONCE: the padded send buffer of a
+    short rank and, on `dst`, one [world * max(counts), ...] receive buffer whose per-rank chunks are the collective's
+    gather list (no per-step allocation or torch.cat on the timed path when all ranks hold the same count; a ragged
+    step compacts into a second preallocated buffer).  The returned tensor is reused by the next call."""
+
+    def __init__(self, counts: List[int], tail: Tuple[int, ...], dtype: torch.dtype, device: torch.device, dst: int = 0, group=None):
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if len(counts) != self.world:
+            raise ValueError("counts must have one entry per rank")
+        self.counts, self.tail, self.dst, self.group = list(counts), tuple(tail), dst, group
+        self.m = max(counts) if counts else 0
+        self.device = torch.device(device)
+        # gloo has no device gather: the CPU rehearsal of the RCCL path stages through host buffers
+        self.host = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
+        wire = torch.device("cpu") if self.host else self.device
+        self.send = torch.zeros((self.m,) + self.tail, dtype=dtype, device=wire) if (counts[self.rank] < self.m or self.host) else None
+        self.recv = self.out = None
+        if self.rank == dst and self.m:
+            self.recv = torch.empty((self.world * self.m,) + self.tail, dtype=dtype, device=wire)
+            self.chunks = list(self.recv.split(self.m, 0))
+            ragged = any(c != self.m for c in counts)
+            if ragged or self.host:
+                self.out = torch.empty((sum(counts),) + self.tail, dtype=dtype, device=self.device)
+
+    def __call__(self, local: torch.Tensor) -> Optional[torch.Tensor]:
+        c = self.counts[self.rank]
+        if local.shape[0] != c or tuple(local.shape[1:]) != self.tail:
+            raise ValueError("rank %d holds %s, FlowGather was built for [%d,%s]" % (self.rank, tuple(local.shape), c, ",".join(map(str, self.tail))))
+        if self.m == 0:
+            return local if self.rank == self.dst else None
+        if self.send is not None:
+            self.send[:c].copy_(local)
+            send = self.send
+        else:
+            send = local.contiguous()
+        if self.rank != self.dst:
+            dist.gather(send, gather_list=None, dst=self.dst, group=self.group)
+            return None
+        dist.gather(send, gather_list=self.chunks, dst=self.dst, group=self.group)
+        if self.out is None:
+            return self.recv                                   # equal counts: rank order == batch order, no copy
+        off = 0
+        for chunk, n in zip(self.chunks, self.counts):
+            self.out[off:off + n].copy_(chunk[:n])
+            off += n
+        return self.out
+
+
+_GATHERS = {}
+
+
 def gather_flows(local: torch.Tensor, counts: List[int], dst: int = 0, group=None) -> Optional[torch.Tensor]:
     """Gather per-rank flow fields [b_r,2,h,w] to `dst`; returns the [sum b_r,2,h,w] batch there, None elsewhere.
 
-    Ranks may hold different counts (ragged tail); shorter shards are padded to the longest for the
-    collective and trimmed on arrival.
-    """
+    Ranks may hold different counts (ragged tail); shorter shards are padded to the longest for the collective and
+    trimmed on arrival.  Buffers are allocated once per (counts, shape, dtype, device) and reused (FlowGather): the
+    result is overwritten by the next call with the same geometry."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if len(counts) != world:
         raise ValueError("counts must have one entry per rank")
     if local.shape[0] != counts[rank]:
         raise ValueError("rank %d holds %d items, counts says %d" % (rank, local.shape[0], counts[rank]))
-    m = max(counts)
-    if m == 0:
-        return local if rank == dst else None
-    send = local
-    if local.shape[0] < m:
-        pad = local.new_zeros((m - local.shape[0],) + tuple(local.shape[1:]))
-        send = torch.cat((local, pad), 0)
-    send = send.contiguous()
-    out_device = send.device
-    if send.is_cuda and dist.get_backend(group) == "gloo":
-        send = send.cpu()                      # gloo has no device gather (CPU rehearsal of the RCCL path)
-    if rank == dst:
-        bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, gather_list=bufs, dst=dst, group=group)
-        return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0).to(out_device)
-    dist.gather(send, gather_list=None, dst=dst, group=group)
-    return None
+    key = (tuple(counts), tuple(local.shape[1:]), local.dtype, str(local.device), dst, id(group))
+    g = _GATHERS.get(key)
+    if g is None:
+        if len(_GATHERS) > 16:
+            _GATHERS.clear()
+        g = _GATHERS[key] = FlowGather(counts, tuple(local.shape[1:]), local.dtype, local.device, dst, group)
+    return g(local)
 
 
 class ShardedFlow:

@@ -14,8 +14,10 @@ containers, registered under the reference's names and in the reference's order,
   * ``warp(x, flo)`` is the fused HIP warp.
 
 Additive constructor keywords: ``normalize_corr`` / ``align_corners`` (SURVEY.md section 0, facts 3
-and 4: defaults reproduce the reference as executed on a current torch; set both True for the
-semantics the published weights were trained with), ``conv_backend`` ('hip' = MFMA implicit-GEMM
+and 4).  The CONSTRUCTOR defaults reproduce the reference's CPU fallback as executed on a current torch
+(un-normalised cost volume, ``grid_sample(align_corners=False)``) -- this project's parity definition;
+the checkpoint-loading factories ``pwc_dc_net(path)`` / ``pwc_dc_net_old(path)`` default to the native
+semantics a checkpoint was trained with (``normalize_corr=True``, see ``_checkpoint_kwargs``), ``conv_backend`` ('hip' = MFMA implicit-GEMM
 kernels, 'torch' = BASELINE config[1], convolutions left to PyTorch-ROCm), ``use_graph``.
 
 Inference only: the HIP path does not build an autograd graph (returned flows have
@@ -23,6 +25,8 @@ Inference only: the HIP path does not build an autograd graph (returned flows ha
 """
 from __future__ import annotations
 
+import warnings
+from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -95,8 +99,13 @@ class PWCDCNet(nn.Module):
                 if m.bias is not None:
                     m.bias.data.zero_()
 
-        self._plans: Dict[Tuple, PwcPlan] = {}
+        # plans (buffers + packed filters, ~0.2 GB per pair at 1024x448) and captured graphs are cached per
+        # (batch, size, ...) key, least recently used first; at most `max_cached_plans` are kept so that a caller with
+        # varying image sizes (harness.estimate_flow) cannot exhaust HBM
+        self.max_cached_plans = 4
+        self._plans: "OrderedDict[Tuple, PwcPlan]" = OrderedDict()
         self._graphs: Dict[Tuple, Tuple] = {}
+        self._warned_detached = False
         self._versions: Optional[Tuple[int, ...]] = None
         self._param_list = None
 
@@ -108,8 +117,18 @@ class PWCDCNet(nn.Module):
             return ops.WarpFunction.apply(x, flo, 1.0, self.align_corners, thr)
         return ops.warp(ops.densify(x), ops.densify(flo), 1.0, self.align_corners, thr)
 
-    @torch.no_grad()
     def forward(self, x: torch.Tensor):
+        if self.training and torch.is_grad_enabled() and not self._warned_detached:
+            # the convolutions have no backward kernels (Correlation and warp do): say so instead of silently handing a
+            # training loop flows that do not require grad
+            warnings.warn("PWCDCNet (HIP path) is inference-only: the training-mode 5-tuple is returned DETACHED "
+                          "(requires_grad=False), so the reference's train*.py loops cannot back-propagate through it. "
+                          "Call it under torch.no_grad() to silence this warning.", stacklevel=2)
+            self._warned_detached = True
+        with torch.no_grad():
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor):
         if x.dim() != 4 or x.shape[1] != 6:
             raise ValueError("expected [B,6,H,W] (two stacked 3-channel images), got %s" % (tuple(x.shape),))
         if not x.is_cuda:
@@ -150,6 +169,8 @@ class PWCDCNet(nn.Module):
             self._versions = ver
         key = self._key(x)
         plan = self._plans.get(key)
+        if plan is not None:
+            self._plans.move_to_end(key)
         if plan is None:
             params = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
             for k, v in params.items():
@@ -168,6 +189,9 @@ class PWCDCNet(nn.Module):
                 plan = PwcPlan(params, x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype, self.md,
                                self.normalize_corr, self.align_corners, self.conv_backend, self.variant)
             self._plans[key] = plan
+            while len(self._plans) > max(1, int(self.max_cached_plans)):
+                old, _ = self._plans.popitem(last=False)
+                self._graphs.pop(old, None)
         return plan
 
     def _run_graph(self, key, plan: PwcPlan, x: torch.Tensor) -> torch.Tensor:
@@ -230,17 +254,38 @@ class PWCDCNet_old(PWCDCNet):
     _pyramid_names = PYRAMID_NAMES_OLD
 
 
+def _checkpoint_kwargs(path: Optional[str], kwargs: dict) -> dict:
+    """A checkpoint was trained against the reference's NATIVE correlation, which divides by kernel_size^2 * C
+    (correlation_cuda_kernel.cu:104,143; reached through Correlation.forward -> CorrelationFunction whenever
+    USE_ONNX_CORRELATION is off, correlation.py:103-117).  The factories therefore default to ``normalize_corr=True``
+    when they load a file; without a file they keep the constructor's default (un-normalised = the semantics of the
+    reference's CPU fallback, this project's parity definition).  Asking for the un-normalised cost volume WITH a
+    checkpoint is allowed but warned about: the cost volume would be C (32..196) times larger than in training."""
+    if path is None:
+        return kwargs
+    kwargs = dict(kwargs)
+    if "normalize_corr" not in kwargs:
+        kwargs["normalize_corr"] = True
+    elif not kwargs["normalize_corr"]:
+        warnings.warn("loading %s with normalize_corr=False: the reference's native correlation (the one checkpoints are "
+                      "trained with) divides by C; un-normalised cost volumes are 32-196x larger and published weights "
+                      "give wrong flow with them" % path, stacklevel=3)
+    return kwargs
+
+
 def pwc_dc_net_old(path: Optional[str] = None, **kwargs) -> PWCDCNet_old:
-    """Factory with the reference's name and argument (PWCNet.py:511-520)."""
-    model = PWCDCNet_old(**kwargs)
+    """Factory with the reference's name and argument (PWCNet.py:511-520); see _checkpoint_kwargs for the default
+    correlation semantics when ``path`` is given."""
+    model = PWCDCNet_old(**_checkpoint_kwargs(path, kwargs))
     if path is not None:
         model.load_state_dict(load_checkpoint(path))
     return model
 
 
 def pwc_dc_net(path: Optional[str] = None, **kwargs) -> PWCDCNet:
-    """Factory with the reference's name and argument (PWCNet.py:497-506)."""
-    model = PWCDCNet(**kwargs)
+    """Factory with the reference's name and argument (PWCNet.py:497-506); see _checkpoint_kwargs for the default
+    correlation semantics when ``path`` is given."""
+    model = PWCDCNet(**_checkpoint_kwargs(path, kwargs))
     if path is not None:
         model.load_state_dict(load_checkpoint(path))
     return model

@@ -123,6 +123,67 @@ def test_correlation_module_and_pybind_shim(dev):
     assert torch.allclose(a2.grad.cpu(), ar.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_forward_native_semantics_vs_oracle(dev, precision):
+    """What an unchanged script gets from models.pwc_dc_net(path): the native (normalised, /C) correlation
+    (correlation_cuda_kernel.cu:104,143), here with align_corners on too (the behaviour published weights were trained
+    under).  No reference-generated golden exists for this mode (the reference's CUDA extension cannot run here), so the
+    oracle -- whose normalised correlation is its golden-pinned un-normalised one divided by C -- is the checker."""
+    import models
+    from opticalflow_amd.weights import synthetic_state_dict
+    import tempfile, os
+    net0 = models.pwc_dc_net()
+    # normalised cost volumes are ~C times smaller: a larger gain keeps |flow| = O(1)
+    sd = synthetic_state_dict(net0.manifest(), seed=5, gain=1.25, bias_std=0.02)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.pth.tar")
+        torch.save({"state_dict": sd}, path)
+        net = models.pwc_dc_net(path, align_corners=True, precision=precision).to(dev).eval()
+    assert net.normalize_corr is True
+    x = seeded_rand((2, 6, 128, 192), 77)
+    with torch.no_grad():
+        ref = O.pwc_forward(sd, x, normalize_corr=True, align_corners=True)
+    got = net(x.to(dev)).cpu()
+    epe, scale = O.epe(got, ref), ref.abs().mean().item()
+    print("native-semantics forward [%s]: EPE %.3e, mean|flow| %.3f" % (precision, epe, scale))
+    assert scale > 0.05
+    assert epe < (1e-3 if precision == "fp32" else 1.4e-3 * max(scale, 0.5))
+    # the drop-in Correlation module is the native operator too
+    from models.correlation_package.correlation import Correlation
+    a, b = seeded_rand((1, 16, 16, 32), 30, -1, 1), seeded_rand((1, 16, 16, 32), 31, -1, 1)
+    y = Correlation(4, 1, 4, 1, 1, 1)(a.to(dev), b.to(dev)).cpu()
+    assert torch.allclose(y, O.correlation(a, b, 4, 1, 4, 1, 1, 1, normalize=True), rtol=1e-5, atol=1e-6)
+
+
+def test_plan_cache_is_bounded_and_training_mode_warns(dev):
+    """plans/graphs are cached per input geometry in an LRU of `max_cached_plans`; a training-mode call with
+    grad enabled says that the returned flows are detached instead of silently feeding a training loop."""
+    import warnings
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    net = PWCDCNet(use_graph=True).to(dev).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
+    net.max_cached_plans = 2
+    xs = [seeded_rand((1, 6, h, w), 90 + i).to(dev) for i, (h, w) in enumerate(((64, 64), (64, 128), (128, 128)))]
+    first = net(xs[0])
+    for x in xs[1:]:
+        net(x)
+    assert len(net._plans) == 2 and len(net._graphs) == 2 and net._key(xs[0]) not in net._plans
+    assert torch.equal(net(xs[0]), first)                       # rebuilt on demand, same bits
+    assert len(net._plans) == 2 and net._key(xs[1]) not in net._plans
+    net.train()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        outs = net(xs[0])
+        assert len(outs) == 5 and not outs[0].requires_grad
+        assert any("inference-only" in str(m.message) for m in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            net(xs[0])
+        assert not w
+
+
 def test_corr_and_warp_fp16_storage(dev):
     """PWC_F16 tensors (fp32 accumulation inside): compare with the oracle on the SAME fp16-rounded inputs.
     Tolerance = half-precision rounding of the result (2^-10 relative) + accumulation noise."""

@@ -170,6 +170,43 @@ def test_drop_in_import_paths():
     assert (m.pad_size, m.kernel_size, m.max_displacement, m.stride1, m.stride2, m.corr_multiply) == (4, 1, 4, 1, 1, 1)
     old = models.pwc_dc_net_old()                      # PWCNet.py:511-520
     assert type(old).__name__ == "PWCDCNet_old" and len(old.state_dict()) == 116
+    # the drop-in module keeps the reference's semantics: native (normalised) unless USE_ONNX_CORRELATION is set
+    assert m.normalize is True
+    import inspect
+    assert "normalize" not in inspect.signature(Correlation.__init__).parameters     # the reference's exact signature
+    import opticalflow_amd.correlation as impl
+    a = torch.randn(1, 6, 10, 12, generator=torch.Generator().manual_seed(3))
+    b = torch.randn(1, 6, 10, 12, generator=torch.Generator().manual_seed(4))
+    impl.USE_ONNX_CORRELATION = True                   # reference fallback (correlation.py:103-110): un-normalised, any device
+    try:
+        assert torch.allclose(m(a, b), O.correlation(a, b, 4, 1, 4, 1, 1, 1), atol=1e-5)
+    finally:
+        impl.USE_ONNX_CORRELATION = False
+
+
+def test_checkpoint_factories_default_to_native_correlation(tmp_path):
+    """a checkpoint is trained against the reference's native correlation (/C, correlation_cuda_kernel.cu:104,143),
+    so pwc_dc_net(path) defaults to normalize_corr=True; without a file the constructor's parity default (un-normalised)
+    stays; an explicit normalize_corr=False with a checkpoint warns."""
+    import warnings
+    import models
+    from opticalflow_amd import PWCDCNet, pwc_dc_net, pwc_dc_net_old
+    from opticalflow_amd.weights import synthetic_state_dict
+    path = str(tmp_path / "w.pth.tar")
+    torch.save(synthetic_state_dict(PWCDCNet().manifest(), seed=1), path)
+    assert PWCDCNet().normalize_corr is False and pwc_dc_net().normalize_corr is False
+    for factory in (pwc_dc_net, models.pwc_dc_net):
+        net = factory(path)
+        assert net.normalize_corr is True and net.corr.normalize is True
+    assert pwc_dc_net(path, normalize_corr=True, align_corners=True).align_corners is True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        net = pwc_dc_net(path, normalize_corr=False)
+        assert net.normalize_corr is False and any("normalize_corr=False" in str(x.message) for x in w)
+    from opticalflow_amd import pwcnet
+    path_old = str(tmp_path / "old.pth.tar")
+    torch.save(synthetic_state_dict(pwcnet.PWCDCNet_old().manifest(), seed=1), path_old)
+    assert pwc_dc_net_old(path_old).normalize_corr is True
 
 
 def test_old_variant_state_dict_and_channel_permutation():

@@ -71,3 +71,68 @@ def test_sharded_flow_world2_gloo(nitems):
     ok = mp.get_context("spawn").Array("i", [0, 0])
     mp.spawn(_worker, args=(2, port, nitems, ok), nprocs=2, join=True)
     assert list(ok) == [1, 1]
+
+
+# ---- BASELINE configs[4]: the KITTI-shaped stream sharded over ranks (kitti.ShardedStream) ---------------------
+def _fake_infer(u8):
+    """stand-in for GraphedInfer (the HIP forward needs a GPU): [n,2,H,W,3] uint8 -> (full [n,2,H,W], quarter [n,2,H/4,W/4])"""
+    f = u8.float().mean(dim=-1)                       # [n,2,H,W]: channel 0 from image 1, channel 1 from image 2
+    return f, f[:, :, ::4, ::4].contiguous()
+
+
+def _stream_pairs(n):
+    g = torch.Generator().manual_seed(9)
+    return [(torch.randint(0, 256, (8, 16, 3), generator=g, dtype=torch.uint8),
+             torch.randint(0, 256, (8, 16, 3), generator=g, dtype=torch.uint8)) for _ in range(n)]
+
+
+def _stream_worker(rank, world, port, nitems, batch, ok):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from opticalflow_amd import kitti
+        pairs = _stream_pairs(nitems)
+        st = kitti.ShardedStream(torch.device("cpu"), batch=batch, infer=_fake_infer, batcher=kitti.HostBatcher)
+        assert list(st.my_indices(nitems)) == list(range(rank, nitems, world))
+        plan = st.step_counts(nitems)
+        assert sum(c[rank] for c in plan) == len(range(rank, nitems, world)) and all(max(c) <= batch for c in plan)
+        seen, got = [], {}
+        for idx, full, gathered in st.run(pairs):
+            seen += idx
+            for k, i in enumerate(idx):                                  # local full-resolution flows
+                assert torch.equal(full[k], _fake_infer(torch.stack(pairs[i])[None])[0][0])
+            if rank == 0:
+                order, flows = gathered
+                assert flows.shape[0] == len(order)
+                for k, i in enumerate(order):
+                    got[i] = flows[k].clone()                            # the gather buffer is reused by the next step
+            else:
+                assert gathered is None
+        assert seen == list(range(rank, nitems, world))
+        if rank == 0:                                                    # every pair of the stream arrived exactly once
+            assert sorted(got) == list(range(nitems))
+            for i in range(nitems):
+                assert torch.equal(got[i], _fake_infer(torch.stack(pairs[i])[None])[1][0])
+        # sharded evaluation (inference_kitti.py:296-314): only (sum EPE, sum Fl, n) travel
+        samples = []
+        for a, b in pairs:
+            gt = _fake_infer(torch.stack((a, b))[None])[0][0].permute(1, 2, 0).numpy().copy()
+            gt[..., 0] += 1.0                                            # EPE exactly 1 px, no outliers
+            samples.append((a, b, gt, np.ones(gt.shape[:2], bool)))
+        epe, fl, n = kitti.evaluate_pairs_sharded(st, samples)
+        assert n == nitems and abs(epe - 1.0) < 1e-6 and fl == 0.0
+        ok[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nitems,batch", [(7, 2), (4, 1), (9, 4)])
+def test_kitti_sharded_stream_world2_gloo(nitems, batch):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ok = mp.get_context("spawn").Array("i", [0, 0])
+    mp.spawn(_stream_worker, args=(2, port, nitems, batch, ok), nprocs=2, join=True)
+    assert list(ok) == [1, 1]
