@@ -133,8 +133,8 @@ def test_forward_native_semantics_vs_oracle(dev, precision):
     from opticalflow_amd.weights import synthetic_state_dict
     import tempfile, os
     net0 = models.pwc_dc_net()
-    # normalised cost volumes are ~C times smaller: a larger gain keeps |flow| = O(1)
-    sd = synthetic_state_dict(net0.manifest(), seed=5, gain=1.25, bias_std=0.02)
+    # normalised cost volumes are ~C times smaller: gain 1.05 instead of 0.85 keeps mean |flow| ~ 1.1 (0.85 gives 0.07)
+    sd = synthetic_state_dict(net0.manifest(), seed=5, gain=1.05, bias_std=0.02)
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "w.pth.tar")
         torch.save({"state_dict": sd}, path)
@@ -146,8 +146,8 @@ def test_forward_native_semantics_vs_oracle(dev, precision):
     got = net(x.to(dev)).cpu()
     epe, scale = O.epe(got, ref), ref.abs().mean().item()
     print("native-semantics forward [%s]: EPE %.3e, mean|flow| %.3f" % (precision, epe, scale))
-    assert scale > 0.05
-    assert epe < (1e-3 if precision == "fp32" else 1.4e-3 * max(scale, 0.5))
+    assert 0.5 < scale < 3.0
+    assert epe < (1e-3 if precision == "fp32" else 1.6e-3 * scale)
     # the drop-in Correlation module is the native operator too
     from models.correlation_package.correlation import Correlation
     a, b = seeded_rand((1, 16, 16, 32), 30, -1, 1), seeded_rand((1, 16, 16, 32), 31, -1, 1)
