@@ -210,6 +210,165 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     }
 }
 
+// ---- 8-wave variant for the large stride-1 layers (levels 2 and 3, context network) ----------------------------------
+// Same LDS images and MFMA loop as above, other residency: a workgroup is EIGHT MFMA waves on a 16-row x 32-col tile (wave w
+// owns rows 2w, 2w+1) x 32*MT couts, with a plain double buffer that every wave fills (each issues its 1/8 of the next
+// chunk's LDS-DMA right after the barrier, as the fp32 kernel does) instead of a dedicated loader wave.  With MT <= 2 the
+// workgroup needs <= 80 KiB of LDS and <= 128 registers, so TWO workgroups share a CU = four MFMA waves per SIMD: one
+// wave's barrier / LDS latency / DMA issue is covered by the other three (PMC on the 5-wave kernel, profiles/
+// r02_f16_pmc_diag.txt: its MFMA waves are parked 25 % of their life and the matrix pipe is busy 62 %).  The taller tile
+// also halves the filter bytes pulled from L2 per flop.
+template <int MT, int D>
+struct G8 {
+    static constexpr int kTileH = 16;
+    static constexpr int kInH = kTileH + 2 * D;
+    static constexpr int kInW = kTileW + 2 * D;
+    static constexpr int kInPieces = 2 * kInH * kInW;              // [kh][row][col]
+    static constexpr int kInWI = (kInPieces + 63) / 64;            // wave-instructions (1 KiB each)
+    static constexpr int kCoutT = 32 * MT;
+    static constexpr int kWWI = 18 * kCoutT / 64;                  // [tap][kh][cout]: 9 * MT, exact
+    static constexpr int kWI = kInWI + kWWI;
+    static constexpr int kPer = (kWI + 7) / 8;                     // per wave and chunk
+    static constexpr int kWOffBytes = kInWI * 1024;
+    static constexpr int kSlotBytes = kWI * 1024;
+    static constexpr int kSmem = 2 * kSlotBytes;
+    static constexpr int kWavesPerSimd = (kSmem <= 80 * 1024 && MT <= 2) ? 4 : 2;
+    static constexpr bool kValid = kSmem <= 160 * 1024;
+};
+
+template <int MT, int D>
+__global__ void __launch_bounds__(512, (G8<MT, D>::kWavesPerSimd))
+conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ wp, const float *__restrict__ bias,
+                     void *__restrict__ yv, int Cg, int H, int W, int Cout, int CoutP,
+                     int tiles_x, int tiles_y, int64_t bsx, int64_t bsy, float slope, int mode) {
+    using G = G8<MT, D>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    int bid = blockIdx.x;
+#ifndef PWC_F16_NO_XCD_MAP
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+#endif
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int g = blockIdx.y;
+    const int ox0 = tx * kTileW;
+    const int oy0 = ty * G::kTileH;
+    const int plane = H * W;
+    const int nchunks = (Cg + 1) / 2;
+    const _Float16 *xb = x + (int64_t)b * bsx;
+
+    // wave-instruction ids of this wave: wave, wave + 8, ...; ids < kInWI read the input, the others the filter slab
+    unsigned off[G::kPer];
+#pragma unroll
+    for (int j = 0; j < G::kPer; ++j) {
+        const int id = j * 8 + wave;
+        if (id < G::kInWI) {
+            const int p = id * 64 + lane;
+            const int kh = p / (G::kInH * G::kInW);
+            const int rem = p % (G::kInH * G::kInW);
+            const int iy = oy0 - D + rem / G::kInW;
+            const int ix = ox0 - D + rem % G::kInW;
+            const bool ok = (p < G::kInPieces) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+            off[j] = ok ? (unsigned)(kh * plane + iy * W + ix) * 16u : kOOB;
+        } else {
+            const int q = (id - G::kInWI) * 64 + lane;
+            const int row = q / G::kCoutT;                    // tap*2 + kh
+            const int co = g * G::kCoutT + q % G::kCoutT;
+            off[j] = (id < G::kWI && co < CoutP) ? (unsigned)(row * CoutP + co) * 16u : kOOB;
+        }
+    }
+    auto issue = [&](int chunk) {
+        const int cgv = min(2, Cg - 2 * chunk);
+        const pwc::v4i32 rin = pwc::make_rsrc(xb + (int64_t)chunk * 2 * plane * 8, cgv * plane * 16);
+        const pwc::v4i32 rw = pwc::make_rsrc(wp + (int64_t)chunk * 18 * CoutP * 8, 18 * CoutP * 16);
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(smem + (chunk & 1) * G::kSlotBytes));
+#pragma unroll
+        for (int j = 0; j < G::kPer; ++j) {
+            const int id = j * 8 + wave;                       // wave-uniform
+            if (id < G::kInWI)     pwc::dma_b128(rin, base + id * 1024, off[j]);
+            else if (id < G::kWI)  pwc::dma_b128(rw, base + id * 1024, off[j]);
+        }
+    };
+
+    const int col = lane & 31;
+    const int kh = lane >> 5;
+    const bool do_leaky = mode & kModeLeaky, out_f32 = mode & kModeOutF32;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            const float bv = bias[min(co, Cout - 1)];
+            acc[mt][0][j] = bv;
+            acc[mt][1][j] = bv;
+        }
+    }
+    issue(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of `chunk` has landed
+        __builtin_amdgcn_s_barrier();                          // ... everyone's has; the other slot is no longer read
+        asm volatile("" ::: "memory");
+        if (chunk + 1 < nchunks) issue(chunk + 1);
+        const unsigned char *cur = smem + (chunk & 1) * G::kSlotBytes;
+        const h8 *in = reinterpret_cast<const h8 *>(cur) + (kh * G::kInH + wave * 2) * G::kInW + col;
+        const h8 *ws = reinterpret_cast<const h8 *>(cur + G::kWOffBytes) + kh * G::kCoutT + col;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            h8 a[MT], bv[2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = ws[tap * 2 * G::kCoutT + mt * 32];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bv[nt] = in[(nt + ky * D) * G::kInW + kx * D];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // LDS reads retired before the next barrier frees the slot
+    }
+
+    const int ox = ox0 + col;
+    const int64_t oplane = (int64_t)H * W;
+    const int cg_out = (Cout + 7) / 8;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int oy = oy0 + wave * 2 + nt;
+        if (oy >= H || ox >= W) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cg = (g * G::kCoutT + mt * 32) / 8 + q;
+                if (cg >= cg_out) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[mt][nt][4 * q + i];
+                    if (do_leaky) v[i] = pwc::leaky(v[i], slope);
+                    if (cg * 8 + 4 * kh + i >= Cout) v[i] = 0.f;
+                }
+                const int64_t at = (int64_t)b * bsy + ((int64_t)cg * oplane + (int64_t)oy * W + ox) * 8 + 4 * kh;
+                if (out_f32) {
+                    *reinterpret_cast<float4 *>(static_cast<float *>(yv) + at) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    h4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = pwc::sat_half(v[i]);
+                    *reinterpret_cast<h4 *>(static_cast<_Float16 *>(yv) + at) = o;
+                }
+            }
+        }
+    }
+}
+
 // wp[cgp][tap][kh][CoutP][8] <- w[co][ci = 8*(2*cgp + kh) + j][tap]   (zero outside Cin / Cout)
 // split = 1 (Cout <= 16, CoutP = 32): row co holds the filter rounded to half, row co + 16 the rounding residual
 // times 2^11 (exact scaling; keeps it out of the subnormal range), so that hi + lo / 2^11 carries ~22 bits of the filter
@@ -306,6 +465,25 @@ int launch16(const Args16 &a) {
     }
 }
 
+template <int MT, int D>
+int launch16w8(const Args16 &a) {
+    using G = G8<MT, D>;
+    static_assert(G::kValid, "8-wave tile does not fit the LDS");
+    const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+    const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
+    const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
+    const int groups = (a.CoutP / 32 + MT - 1) / MT;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
+    auto kern = conv3x3_f16w8_kernel<MT, D>;
+    static pwc::LdsAttrOnce attr;
+    if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(512), G::kSmem, a.stream,
+                       a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, tiles_x, tiles_y,
+                       a.bsx, a.bsy, a.slope, a.mode);
+    pwc::note_kernel("conv3x3_f16w8_kernel", MT, 2, 1, D, 2, 8);
+    return pwc::check_launch("conv3x3_f16w8_kernel");
+}
+
 // Tile choice: widest cout tile that fits the LDS, 3-slot ring if possible, else 2 slots; 16-row tiles (NT = 4) for
 // stride-1 layers with >= 64 couts once the grid is large enough to keep every CU busy with them.
 // PWC_CONV16F_MT / PWC_CONV16F_RING / PWC_CONV16F_NT override (tuning).
@@ -320,6 +498,33 @@ int dispatch16(const Args16 &a) {
     static const int forced_r = [] { const char *e = getenv("PWC_CONV16F_RING"); return (e && *e) ? atoi(e) : 0; }();
     static const int forced_nt = [] { const char *e = getenv("PWC_CONV16F_NT"); return (e && *e) ? atoi(e) : 0; }();
     const int t32 = a.CoutP / 32;
+    // 8-wave kernel (stride 1, dilation <= 8) where it measured faster than the 5-wave one (profiles/r02_f16_w8_sweep.txt,
+    // batch 16): dilation 1 with >= 64 couts (128 couts run as two 64-cout groups so that two workgroups share a CU:
+    // conv2_0 -18 %, conv2_1 -16 %, dc_conv1 -4 %, level 3 -12..-17 %), 32-cout layers with a long K on large maps
+    // (conv2_4 -4 %), and the 96-cout dilation-8 layer (dc_conv4 -23 %).  Dilation 2 / 4 need > 80 KiB per workgroup for
+    // the double buffer (one workgroup per CU: no gain) and stay on the 5-wave kernel.
+    // PWC_CONV16F_W8: unset = this rule, 0 = off, N = force cout tiles of 32*N (read per call: tests flip it).
+    if constexpr (S == 1 && D <= 8) {
+        const char *e = getenv("PWC_CONV16F_W8");
+        const int w8 = (e && *e) ? atoi(e) : -1;
+        const int64_t tiles16w = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 15) / 16);
+        if (w8 != 0 && !(a.mode & kModeSplitW) && tiles16w >= 256) {
+            int mt = 0;
+            if (w8 > 0) {
+                mt = min(w8, t32 == 3 ? 3 : t32);
+            } else if (D == 1) {
+                if (t32 >= 4 || t32 == 2) mt = 2;
+                else if (t32 == 3) mt = 3;
+                else if (tiles16w >= 512 && (a.Cg + 1) / 2 >= 8) mt = 1;
+            } else if (D == 8 && t32 == 3) {
+                mt = 3;
+            }
+            if (mt >= 4 && t32 >= 4) { if constexpr (G8<4, D>::kValid) return launch16w8<4, D>(a); }
+            if (mt == 3) { if constexpr (G8<3, D>::kValid) return launch16w8<3, D>(a); }
+            if (mt >= 2 && t32 >= 2) { if constexpr (G8<2, D>::kValid) return launch16w8<2, D>(a); }
+            if (mt >= 1) { if constexpr (G8<1, D>::kValid) return launch16w8<1, D>(a); }
+        }
+    }
     int want = forced_mt > 0 ? min(forced_mt, t32) : min(t32, 4);
     if (a.mode & kModeSplitW) want = 1;
     // small grids (levels 6-4, batch-1 inference): narrower cout tiles = more workgroups; a workgroup's K loop is then

@@ -79,6 +79,46 @@ def test_conv3x3_f16_vs_torch(dev, case):
     assert torch.equal(again, yc)                                          # deterministic
 
 
+W8_CASES = [
+    # (B, Cin, Cout, H, W, dilation, act) -- grids of >= 256 16-row tiles so that the 8-wave kernel is taken
+    (16, 117, 128, 64, 256, 1, True),
+    (16, 24, 64, 60, 250, 1, True),             # ragged right / bottom edges, 64 couts
+    (8, 40, 96, 112, 250, 2, True),             # 96 couts, dilation 2
+    (16, 64, 32, 64, 256, 4, False),            # dilation 4, no activation
+    (16, 16, 50, 64, 256, 8, True),             # dilation 8, Cout not a multiple of 8 (zero pad channels in the last group)
+    (16, 565, 128, 64, 128, 1, True),           # 71 channel groups: ragged last pair
+]
+
+
+@pytest.mark.parametrize("w8", ["1", "2", "4"])
+@pytest.mark.parametrize("case", W8_CASES)
+def test_conv3x3_f16_eight_wave_kernel(dev, case, w8, monkeypatch):
+    """conv3x3_f16w8_kernel (8 MFMA waves, 16-row tiles, double buffer filled by all waves) against torch fp64, for every
+    cout-tile width; same bound as the 5-wave kernel, deterministic, and bit-identical to it (same fp32 summation order)."""
+    from opticalflow_amd import _lib, ops_f16 as F16
+    B, cin, cout, H, W, dil, act = case
+    x = seeded_rand((B, cin, H, W), 610, -1, 1).half().float()
+    w = (seeded_rand((cout, cin, 3, 3), 611, -1, 1) * (2.0 / (cin * 9)) ** 0.5).half().float()
+    bias = seeded_rand((cout,), 612, -0.5, 0.5)
+    xc = F16.to_c8(x.to(dev))
+    wp = F16.pack_conv3x3_f16(w.to(dev))
+    monkeypatch.setenv("PWC_CONV16F_W8", "0")
+    base = F16.conv3x3_f16(xc, wp, bias.to(dev), cin, cout, dilation=dil, leaky_slope=0.1 if act else None)
+    assert "conv3x3_f16_kernel" in _lib.load().pwc_last_conv_kernel().decode()
+    monkeypatch.setenv("PWC_CONV16F_W8", w8)
+    yc = F16.conv3x3_f16(xc, wp, bias.to(dev), cin, cout, dilation=dil, leaky_slope=0.1 if act else None)
+    assert "conv3x3_f16w8_kernel" in _lib.load().pwc_last_conv_kernel().decode()
+    assert torch.equal(yc, base)
+    ref = F.conv2d(x[:2].double(), w.double(), bias.double(), padding=dil, dilation=dil)
+    if act:
+        ref = F.leaky_relu(ref, 0.1)
+    got = F16.from_c8(yc[:2], cout).cpu().double()
+    assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+    if cout % 8:
+        assert (yc[:, -1, :, :, cout % 8:] == 0).all()
+    assert torch.equal(F16.conv3x3_f16(xc, wp, bias.to(dev), cin, cout, dilation=dil, leaky_slope=0.1 if act else None), yc)
+
+
 def test_conv3x3_f16_arena_slices_and_errors(dev):
     """input = channel-group suffix of an arena, output = a group slice of the same arena (the DenseNet concat)."""
     from opticalflow_amd import PwcHipError, ops_f16 as F16

@@ -147,7 +147,9 @@ def test_forward_native_semantics_vs_oracle(dev, precision):
     epe, scale = O.epe(got, ref), ref.abs().mean().item()
     print("native-semantics forward [%s]: EPE %.3e, mean|flow| %.3f" % (precision, epe, scale))
     assert 0.5 < scale < 3.0
-    assert epe < (1e-3 if precision == "fp32" else 1.6e-3 * scale)
+    # fp16: these gain-1.05 weights amplify rounding noise 2.5x more than the golden (gain 0.85) ones -- the CPU emulation of
+    # nothing but the half roundings (tests/f16_error_budget.py, normalised mode) gives 3.8e-3 here; measured 3.78e-3
+    assert epe < (1e-3 if precision == "fp32" else 4.5e-3 * scale)
     # the drop-in Correlation module is the native operator too
     from models.correlation_package.correlation import Correlation
     a, b = seeded_rand((1, 16, 16, 32), 30, -1, 1), seeded_rand((1, 16, 16, 32), 31, -1, 1)
