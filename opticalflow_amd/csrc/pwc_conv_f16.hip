@@ -218,13 +218,7 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
 // wave's barrier / LDS latency / DMA issue is covered by the other three (PMC on the 5-wave kernel, profiles/
 // r02_f16_pmc_diag.txt: its MFMA waves are parked 25 % of their life and the matrix pipe is busy 62 %).  The taller tile
 // also halves the filter bytes pulled from L2 per flop.
-// SH = 1 runs the same tile on v_mfma_f32_16x16x32_f16 (16 cout x 16 pixel x 32 k): the kernel is POWER-bound (PMC: the
-// matrix pipe is 77 % busy and the chip answers with 1.25 GHz), and the MI355X guide measures that the 16x16x32 shape holds a
-// ~12-15 % higher clock than 32x32x16 at equal cycles per flop.  A lane quarter kq = lane >> 4 carries k-group
-// (tap, kh) = (2m + (kq >> 1), kq & 1) of MFMA step m = 0..4, i.e. row 4m + kq of the [tap][kh][cout] filter image; the ninth
-// tap has no partner, so rows 18, 19 of that image are zero-filled (range-checked DMA) and the fifth step runs half empty.
-typedef float f32x4v16 __attribute__((ext_vector_type(4)));
-
+// (A v_mfma_f32_16x16x32_f16 form of this kernel was built and measured 2-10 % slower: profiles/r02_f16_mfma_shape_experiment.txt.)
 template <int MT, int D, int SH = 0>
 struct G8 {
     static constexpr int kTileH = 16;
@@ -307,7 +301,7 @@ conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict_
     const int64_t oplane = (int64_t)H * W;
     const int cg_out = (Cout + 7) / 8;
 
-    if constexpr (SH == 0) {
+    {
         const int col = lane & 31;
         const int kh = lane >> 5;
         f32x16 acc[MT][2];
@@ -374,87 +368,6 @@ conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict_
                         for (int i = 0; i < 4; ++i) o[i] = pwc::sat_half(v[i]);
                         *reinterpret_cast<h4 *>(static_cast<_Float16 *>(yv) + at) = o;
                     }
-                }
-            }
-        }
-    } else {
-        // ---- 16x16x32: wave tile = (2*MT cout tiles of 16) x (4 pixel tiles: 2 rows x 2 column halves) -------------------
-        constexpr int CT = 2 * MT;
-        const int p16 = lane & 15;
-        const int kq = lane >> 4;
-        f32x4v16 acc[CT][4];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = g * G::kCoutT + ct * 16 + 4 * kq + r;
-                const float bv = bias[min(co, Cout - 1)];
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt) acc[ct][pt][r] = bv;
-            }
-        }
-        // per-lane tap offsets (in 16-byte pieces) of the five MFMA steps: tap = 2m + (kq >> 1), clamped to tap 8 for the
-        // empty half of step 4 (any finite operand: its filter rows are zero)
-        // (computed per step from the lane's `odd` flag instead of being kept in five registers: the 128-register budget of
-        // four waves per SIMD is tight)
-        const int odd = kq >> 1;
-        const int in_lane = ((kq & 1) * G::kInH + wave * 2) * G::kInW + p16;        // + pixel-tile and tap offsets
-        issue(0);
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (chunk + 1 < nchunks) issue(chunk + 1);
-            const unsigned char *cur = smem + (chunk & 1) * G::kSlotBytes;
-            const h8 *in = reinterpret_cast<const h8 *>(cur) + in_lane;
-            const h8 *ws = reinterpret_cast<const h8 *>(cur + G::kWOffBytes) + kq * G::kCoutT + p16;
-#pragma unroll
-            for (int m = 0; m < 5; ++m) {
-                const int t0 = 2 * m, t1 = (2 * m + 1 > 8) ? 8 : 2 * m + 1;        // constants after unrolling
-                const int o0 = ((t0 / 3) * D) * G::kInW + (t0 % 3) * D, o1 = ((t1 / 3) * D) * G::kInW + (t1 % 3) * D;
-                const h8 *inm = in + (odd ? o1 : o0);
-                h8 bv[4];
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt) bv[pt] = inm[(pt >> 1) * G::kInW + (pt & 1) * 16];
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const h8 a = ws[4 * m * G::kCoutT + ct * 16];
-#pragma unroll
-                    for (int pt = 0; pt < 4; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bv[pt], acc[ct][pt], 0, 0, 0);
-                }
-                // four waves share the SIMD: keep the next step's operand loads from being hoisted over this step's MFMAs
-                // (they would not fit the 128-register budget; the other three waves cover the LDS latency)
-                if constexpr (G::kWavesPerSimd == 4) __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        // D: column = lane & 15 (pixel), row = 4*kq + reg (cout): one lane holds 4 consecutive couts of one pixel
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            const int oy = oy0 + wave * 2 + (pt >> 1);
-            const int ox = ox0 + (pt & 1) * 16 + p16;
-            if (oy >= H || ox >= W) continue;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int co0 = g * G::kCoutT + ct * 16 + 4 * kq;
-                const int cg = co0 >> 3;
-                if (cg >= cg_out) continue;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[ct][pt][i];
-                    if (do_leaky) v[i] = pwc::leaky(v[i], slope);
-                    if (co0 + i >= Cout) v[i] = 0.f;
-                }
-                const int64_t at = (int64_t)b * bsy + ((int64_t)cg * oplane + (int64_t)oy * W + ox) * 8 + (co0 & 7);
-                if (out_f32) {
-                    *reinterpret_cast<float4 *>(static_cast<float *>(yv) + at) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    h4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = pwc::sat_half(v[i]);
-                    *reinterpret_cast<h4 *>(static_cast<_Float16 *>(yv) + at) = o;
                 }
             }
         }
@@ -561,13 +474,7 @@ template <int MT, int D, int SH>
 int launch16w8s(const Args16 &a);
 
 template <int MT, int D>
-int launch16w8(const Args16 &a) {
-    // PWC_CONV16F_SHAPE: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16 (read per call: tests flip it)
-    const char *e = getenv("PWC_CONV16F_SHAPE");
-    const int sh = (e && *e) ? atoi(e) : 0;
-    if constexpr (G8<MT, D, 1>::kValid) if (sh == 1) return launch16w8s<MT, D, 1>(a);
-    return launch16w8s<MT, D, 0>(a);
-}
+int launch16w8(const Args16 &a) { return launch16w8s<MT, D, 0>(a); }
 
 template <int MT, int D, int SH>
 int launch16w8s(const Args16 &a) {
