@@ -150,6 +150,15 @@ int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64
 int pwc_image_conv_s2_c8_f16(const void *x, const void *w, const void *bias, void *y, int B, int H, int W,
                              float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream);
 
+/* conv1a -> conv1aa -> conv1b -> conv2a (PWCNet.py:52-55 as used at :184-187: the level-1 features feed conv2a only) in ONE
+ * launch: x float32 [B,3,H,W] -> y c8 halves [B][4][H2][W2][8] with H1 = (H-1)/2+1, H2 = (H1-1)/2+1 (same for W).  The three
+ * level-1 maps live in LDS per 8x16 output tile.  wpack: pwc_pyramid1_f16_packed_bytes() bytes of halves = conv1a as
+ * [k/8][cout 16][k%8] (k = ci*9+ky*3+kx, 27 padded to 32), then conv1aa, conv1b ([20 rows = tap*2+kh, last two zero][16][8])
+ * and conv2a ([20][32][8]); bias: float[80] = conv1a | conv1aa | conv1b | conv2a.  LeakyReLU(leaky_slope) after every layer. */
+int64_t pwc_pyramid1_f16_packed_bytes(void);
+int pwc_pyramid1_fused_f16(const void *x, const void *wpack, const void *bias, void *y, int B, int H, int W,
+                           float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream);
+
 /* PWC-Net's cost volume (pad 4, kernel 1, max displacement 4, strides 1) on c8 f16 tensors, fp32 accumulation:
  * in1,in2: [B][ceil(C/8)][H][W][8]; out: [B][11][H][W][8] = 81 displacement channels ((dy+4)*9+(dx+4)) + 7 zeros.
  * flags: PWC_CORR_NORMALIZE (divide by C instead of multiplying by corr_multiply), PWC_ACT_LEAKY. */

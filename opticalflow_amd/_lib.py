@@ -50,6 +50,9 @@ SIGNATURES = {
     "pwc_c8_f16_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_image_conv_s2_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                          c_int64, c_int64, c_void_p]),
+    "pwc_pyramid1_f16_packed_bytes": (c_int64, []),
+    "pwc_pyramid1_fused_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                       c_int64, c_int64, c_void_p]),
     "pwc_corr81_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_uint, c_float,
                                   c_int64, c_int64, c_int64, c_void_p]),
     "pwc_warp_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float,

@@ -9,6 +9,8 @@
 //                      chunk of 4 channel groups is staged by LDS-DMA (zero padding = range check).
 //   warp_c8_kernel   : PWCDCNet.warp (models/PWCNet.py:141-177), same coordinate arithmetic and mask rule as the fp32
 //                      kernel (pwc_warp.hip); a tap is one 16-byte gather per channel group.
+#include <stdlib.h>
+
 #include "pwc_common.h"
 
 namespace {
@@ -341,7 +343,9 @@ extern "C" int pwc_corr81_c8_f16(const void *in1, const void *in2, void *out, in
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr81_c8_f16: grid too large");
     const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
-    if (nblk < 256) {                                     // fewer tiles than CUs: one thread per output value instead
+    // few tiles: one thread per output value instead (PWC_CORR16_DIRECT_BELOW overrides the tile-count threshold)
+    static const int direct_below = [] { const char *e = getenv("PWC_CORR16_DIRECT_BELOW"); return (e && *e) ? atoi(e) : 100; }();   // level 4 at batch 16 (128 tiles): tiled 25 us vs direct 38 us; level 5 (32 tiles): direct 15 vs 30
+    if (nblk < direct_below) {
         const int64_t total = (int64_t)B * plane * 88;
         hipLaunchKernelGGL(corr81_c8_direct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                            static_cast<const _Float16 *>(in1), static_cast<const _Float16 *>(in2), static_cast<_Float16 *>(out),

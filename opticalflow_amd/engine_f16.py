@@ -24,6 +24,7 @@ threshold.  Input/outputs stay float32 NCHW like the reference's interface.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -76,7 +77,7 @@ def _phys_index(level: int, nd: int = 81) -> torch.Tensor:
 
 class PwcPlanF16:
     def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device, md: int = 4,
-                 normalize_corr: bool = False, align_corners: bool = False, variant: str = "dc"):
+                 normalize_corr: bool = False, align_corners: bool = False, variant: str = "dc", fuse_pyramid1: bool = True):
         if variant not in ("dc", "old"):
             raise ValueError("variant must be 'dc' or 'old'")
         self.variant = variant
@@ -92,7 +93,11 @@ class PwcPlanF16:
         hk = dict(device=device, dtype=torch.float16)
         self.size = {l: (H >> l, W >> l) for l in range(1, 7)}
         self.pyr_a, self.pyr_b = {}, {}
+        # PWC_F16_FUSE_PYR1=0 keeps the layer-by-layer first level (A/B runs, tests)
+        self.fuse_pyr1 = variant == "dc" and fuse_pyramid1 and os.environ.get("PWC_F16_FUSE_PYR1", "1") != "0"
         for l in range(1, 7):
+            if l == 1 and self.fuse_pyr1:
+                continue                                  # the level-1 maps live in LDS (ops_f16.pyramid1_fused)
             h, w = self.size[l]
             g = _groups(PYRAMID_CH[l])
             self.pyr_a[l] = torch.zeros((self._slots(B), g, h, w, 8), **hk)
@@ -138,6 +143,13 @@ class PwcPlanF16:
         # conv1a (3 -> 16, stride 2) runs straight from the float32 image (ops_f16.image_conv_s2): keep its raw filters
         self.w1a = p["conv1a.0.weight"].contiguous()
         self.b1a = p["conv1a.0.bias"].contiguous()
+        # PWCDCNet: conv1a -> conv1aa -> conv1b -> conv2a as one kernel, the level-1 maps never leave the CU
+        # (ops_f16.pyramid1_fused; PWCDCNet_old has no conv1aa and keeps the layer-by-layer path)
+        self.pyr1 = None
+        if self.fuse_pyr1:
+            self.pyr1 = F16.pack_pyramid1(self.w1a, self.b1a, p["conv1aa.0.weight"].contiguous(), p["conv1aa.0.bias"],
+                                          p["conv1b.0.weight"].contiguous(), p["conv1b.0.bias"],
+                                          p["conv2a.0.weight"].contiguous(), p["conv2a.0.bias"])
         for l, names in enumerate(self.pyramid_names, start=1):
             for i, n in enumerate(names):
                 if n is None or (l == 1 and i == 0):
@@ -213,11 +225,16 @@ class PwcPlanF16:
         prev = None
         for l in range(1, 7):
             na, naa, nb = self.pyramid_names[l - 1]
+            if l == 1 and self.pyr1 is not None:
+                continue                                                   # level 1 + conv2a are one launch below
             a, bb = self.pyr_a[l][lo:hi], self.pyr_b[l][lo:hi]
             first = self.pyr_a[l] if naa is not None else self.pyr_b[l]   # three convs a -> bb -> a; PWCDCNet_old: bb -> a
             if l == 1:
                 for img, s0, s1 in images:
                     F16.image_conv_s2(img, self.w1a, self.b1a, LEAKY, out=first[s0:s1])
+            elif l == 2 and self.pyr1 is not None:
+                for img, s0, s1 in images:
+                    F16.pyramid1_fused(img, self.pyr1[0], self.pyr1[1], LEAKY, out=first[s0:s1])
             else:
                 self._conv(na, prev, first[lo:hi], stride=2)
             if naa is not None:

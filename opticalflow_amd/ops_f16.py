@@ -218,3 +218,54 @@ def image_conv_s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, lea
                                                   float(leaky_slope), x.stride(0) if B > 1 else 3 * H * W, bso, _stream(x))
     check(rc, "pwc_image_conv_s2_c8_f16")
     return out
+
+
+def pack_pyramid1(w1a: torch.Tensor, b1a: torch.Tensor, w1aa: torch.Tensor, b1aa: torch.Tensor, w1b: torch.Tensor,
+                  b1b: torch.Tensor, w2a: torch.Tensor, b2a: torch.Tensor):
+    """Filters / biases of conv1a, conv1aa, conv1b, conv2a (nn.Conv2d layouts, float32, device) -> (packed halves, biases
+    float32[80]) for pyramid1_fused: per layer the [tap*2 + kh][cout][8 channels] image the kernel's 16x16x32 MFMA steps read
+    (20 rows, the last two zero); conv1a as [k/8][cout][k%8] with k = ci*9 + ky*3 + kx padded from 27 to 32."""
+    for t, shp in ((w1a, (16, 3, 3, 3)), (w1aa, (16, 16, 3, 3)), (w1b, (16, 16, 3, 3)), (w2a, (32, 16, 3, 3))):
+        _require_device(t, "weight")
+        if tuple(t.shape) != shp or t.dtype != torch.float32:
+            raise ValueError("expected float32 %s, got %s %s" % (shp, t.dtype, tuple(t.shape)))
+    dev = w1a.device
+    k1 = torch.zeros((32, 16), device=dev)
+    k1[:27] = w1a.reshape(16, 27).t()
+    parts = [k1.view(4, 8, 16).permute(0, 2, 1).reshape(-1)]
+    for w in (w1aa, w1b, w2a):
+        co = w.shape[0]
+        img = torch.zeros((20, co, 8), device=dev)
+        img[:18] = w.reshape(co, 2, 8, 9).permute(3, 1, 0, 2).reshape(18, co, 8)       # (tap, kh, cout, j)
+        parts.append(img.reshape(-1))
+    packed = torch.cat(parts).to(torch.float16).contiguous()
+    need = _lib.load().pwc_pyramid1_f16_packed_bytes()
+    assert packed.numel() * 2 == need, (packed.numel() * 2, need)
+    bias = torch.cat([b.reshape(-1).float() for b in (b1a, b1aa, b1b, b2a)]).contiguous()
+    return packed, bias
+
+
+def pyramid1_fused(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, leaky_slope: float = 0.1,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv2a(conv1b(conv1aa(conv1a(x)))) (PWCNet.py:52-55,184-187) in one launch: x float32 [B,3,H,W] (dense planes, free
+    batch stride) -> c8 halves [B,4,H/4,W/4,8]; `packed`, `bias` from pack_pyramid1.  The level-1 maps stay in LDS."""
+    _require_device(x, "x")
+    if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x[0].is_contiguous():
+        raise ValueError("x must be float32 [B,3,H,W] with dense planes")
+    lib = _lib.load()
+    if packed.dtype != torch.float16 or packed.numel() * 2 != lib.pwc_pyramid1_f16_packed_bytes() or bias.numel() != 80 \
+            or bias.dtype != torch.float32 or packed.device != x.device or bias.device != x.device:
+        raise ValueError("packed / bias do not come from pack_pyramid1 on %s" % x.device)
+    B, _, H, W = x.shape
+    h1, w1 = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    h2, w2 = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B, 4, h2, w2, 8), dtype=torch.float16, device=x.device)
+    elif tuple(out.shape) != (B, 4, h2, w2, 8):
+        raise ValueError("out must be %s" % ((B, 4, h2, w2, 8),))
+    bso = _c8_bstride(out, "out")
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_pyramid1_fused_f16(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+                                        float(leaky_slope), x.stride(0) if B > 1 else 3 * H * W, bso, _stream(x))
+    check(rc, "pwc_pyramid1_fused_f16")
+    return out

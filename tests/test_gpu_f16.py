@@ -361,6 +361,39 @@ def test_image_conv_s2_vs_torch(dev):
         assert (got - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 128), (1, 100, 150), (3, 37, 70), (2, 448, 1024)])
+def test_pyramid1_fused_vs_layer_by_layer(dev, B, H, W):
+    """conv1a -> conv1aa -> conv1b -> conv2a as ONE kernel (level-1 maps in LDS, halos recomputed per tile) against the same four
+    layers run one by one (image_conv_s2 + three MFMA convs) and against torch fp64 with every map rounded to half where
+    the kernels round.  The fused conv1a reads the image as halves (the layer-by-layer one in fp32): tolerance 4e-3 of the range;
+    odd sizes exercise the zero-padding rule (map values outside the image are ZERO, not convolution results)."""
+    from opticalflow_amd import ops_f16 as F16
+    x = seeded_rand((B, 6, H, W), 700)                                   # pair tensor: the two images are batch-strided views
+    ws = {n: (seeded_rand((co, ci, 3, 3), 701 + k, -1, 1) * (2.0 / (ci * 9)) ** 0.5, seeded_rand((co,), 711 + k, -0.3, 0.3))
+          for k, (n, ci, co) in enumerate((("1a", 3, 16), ("1aa", 16, 16), ("1b", 16, 16), ("2a", 16, 32)))}
+    xd = x.to(dev)
+    dw = {n: (w.to(dev), b.to(dev)) for n, (w, b) in ws.items()}
+    packed, bias = F16.pack_pyramid1(*dw["1a"], *dw["1aa"], *dw["1b"], *dw["2a"])
+    for half in (slice(0, 3), slice(3, 6)):
+        got_c8 = F16.pyramid1_fused(xd[:, half], packed, bias)
+        t = F16.image_conv_s2(xd[:, half], *dw["1a"])
+        for n, st in (("1aa", 1), ("1b", 1), ("2a", 2)):
+            t = F16.conv3x3_f16(t, F16.pack_conv3x3_f16(dw[n][0]), dw[n][1], dw[n][0].shape[1], dw[n][0].shape[0], stride=st)
+        assert got_c8.shape == t.shape
+        got, ref_hip = F16.from_c8(got_c8, 32).cpu().double(), F16.from_c8(t, 32).cpu().double()
+        r = x[:, half].half().double()                                    # torch fp64 statement with the same roundings
+        for n, st in (("1a", 2), ("1aa", 1), ("1b", 1), ("2a", 2)):
+            wq = ws[n][0].half().double()
+            r = F.leaky_relu(F.conv2d(r, wq, ws[n][1].double(), stride=st, padding=1), 0.1).half().double()
+        scale = max(1.0, r.abs().max().item())
+        assert got.shape == r.shape
+        assert (got - r).abs().max().item() <= 2e-3 * scale, (got - r).abs().max().item()
+        assert (got - ref_hip).abs().max().item() <= 4e-3 * scale
+        assert torch.equal(F16.pyramid1_fused(xd[:, half], packed, bias), got_c8)     # deterministic
+    with pytest.raises(ValueError):
+        F16.pyramid1_fused(xd[:, :4], packed, bias)
+
+
 def test_forward_fp16_old_variant(dev):
     """PWCDCNet_old through the half-precision plan.  Levels 6..3 must agree with the fp32 plan of the same model to
     1e-2 relative.  At level 2 of the 64x64 golden input (a 16x16 map) the warp's hard validity threshold (0.999 for this
