@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 4
+#define PWC_ABI_VERSION 5
 
 /* element types */
 #define PWC_F32 0
@@ -76,7 +76,11 @@ int pwc_corr_fwd(const void *in1, const void *in2, void *out,
                  int64_t in1_bstride, int64_t in2_bstride, int64_t out_bstride,
                  void *stream);
 
-/* Gradients of pwc_corr_fwd w.r.t. in1 and in2 (no fused activation; same scale rule as forward). */
+/* Gradients of pwc_corr_fwd w.r.t. in1 and in2 (no fused activation; same scale rule as forward), for ANY
+ * (pad_size, kernel_size, max_disp, stride1, stride2) like the reference's backward (correlation_cuda_kernel.cu:150-334);
+ * grad_out: [B, D*D, outH, outW] contiguous, in*, grad_in*: [B,C,H,W] contiguous.  Gather form with a fixed summation
+ * order (deterministic, no atomics).  PWC-Net's configuration in fp32 runs an LDS-tiled kernel (one thread per pixel,
+ * 81 + 81 grad_out values in registers, both inputs streamed through LDS with their halos). */
 int pwc_corr_bwd(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,
                  int B, int C, int H, int W,
                  int pad_size, int kernel_size, int max_disp, int stride1, int stride2,
@@ -93,14 +97,19 @@ int pwc_warp_fwd(const void *x, const void *flo, void *out,
                  int64_t x_bstride, int64_t flo_bstride, int64_t out_bstride,
                  void *stream);
 
-/* Gradients of pwc_warp_fwd w.r.t. x and flo (contiguous f32 tensors; grad_x is zeroed here, then accumulated
- * with atomics).  The validity mask is a constant, as in the reference, whose in-place thresholding
- * (PWCNet.py:174-175) cuts the mask's graph; what autograd derives for PWCNet.py:141-177 is otherwise
- * reproduced: d/dx through the bilinear taps, d/dflo through the sample coordinates. */
+/* Gradients of pwc_warp_fwd w.r.t. x and flo (contiguous f32 tensors).  The validity mask is a constant, as in the
+ * reference, whose in-place thresholding (PWCNet.py:174-175) cuts the mask's graph; what autograd derives for
+ * PWCNet.py:141-177 is otherwise reproduced: d/dx through the bilinear taps (a scatter: which output pixels sample a source
+ * pixel depends on the flow), d/dflo through the sample coordinates.
+ * workspace (device, 8-byte aligned, >= pwc_warp_bwd_workspace_bytes): the scatter accumulates 64-bit FIXED-POINT integers
+ * there (integer addition is associative -> bit-reproducible grad_x whatever order the atomics arrive in; resolution 2^-40
+ * of the largest |grad_out|) and grad_x is written once at the end.  workspace == NULL: grad_x is zeroed and accumulated
+ * with float atomics like torch's grid_sample backward (summation order, hence the last bits, not fixed). */
+int64_t pwc_warp_bwd_workspace_bytes(int B, int C, int H, int W);
 int pwc_warp_bwd(const void *x, const void *flo, const void *grad_out, void *grad_x, void *grad_flo,
                  int B, int C, int H, int W,
                  float flow_scale, int align_corners, float mask_threshold, int dtype,
-                 void *stream);
+                 void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Bytes needed for the packed (kernel-native) form of a [Cout,Cin,3,3] filter bank. */
 int64_t pwc_conv3x3_packed_bytes(int Cin, int Cout, int dtype);

@@ -454,12 +454,22 @@ corr_generic_kernel(const T *__restrict__ in1, const T *__restrict__ in2, T *__r
     out[(int64_t)b * bso + (int64_t)tc * oh * ow + (int64_t)oy * ow + ox] = from_f32<T>(v);
 }
 
-// ---- backward (kernel_size 1, stride1 1): gather form, one thread per input element ----------
+// ---- backward ------------------------------------------------------------------------------------------------
+// Gradients of the cost volume w.r.t. both inputs (reference correlation_cuda_kernel.cu:150-334: one kernel per input
+// and per batch item, scatter-free because it loops over the outputs that touched an input element).  Both kernels
+// here are GATHERS with a fixed summation order: deterministic, no atomics.
+//
+// Generic form, any (pad, kernel_size, max_disp, stride1, stride2): one thread per input element (b, c, y, x).
+//   forward: out[tc, oy, ox] += in1[c, y1+j, x1+i] * in2[c, y1+tj*s2+j, x1+ti*s2+i],  y1 = oy*s1 + max_disp - pad
+//   d in1[c, ya, xa] = sum_{tc, j, i} gout[tc, (ya - j - max_disp + pad)/s1, ...] * in2[c, ya + tj*s2, xa + ti*s2]
+//   d in2[c, yb, xb] = sum_{tc, j, i} gout[tc, (yb - tj*s2 - j - max_disp + pad)/s1, ...] * in1[c, yb - tj*s2, xb - ti*s2]
+// (terms whose output index is fractional / out of range or whose partner pixel lies outside the image vanish).
 template <typename T>
 __global__ void __launch_bounds__(256)
-corr_bwd_kernel(const T *__restrict__ in1, const T *__restrict__ in2, const T *__restrict__ gout,
-                T *__restrict__ g1, T *__restrict__ g2,
-                int C, int H, int W, int drad, int s2, int64_t total, float scale) {
+corr_bwd_generic_kernel(const T *__restrict__ in1, const T *__restrict__ in2, const T *__restrict__ gout,
+                        T *__restrict__ g1, T *__restrict__ g2,
+                        int C, int H, int W, int oh, int ow, int pad, int krad, int max_disp, int s1, int s2, int drad,
+                        int64_t total, float scale) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int x = (int)(idx % W);
@@ -469,27 +479,106 @@ corr_bwd_kernel(const T *__restrict__ in1, const T *__restrict__ in2, const T *_
     const int c = (int)(t % C);
     const int b = (int)(t / C);
     const int Dd = 2 * drad + 1;
-    const int64_t plane = (int64_t)H * W;
-    const T *go = gout + (int64_t)b * Dd * Dd * plane;
+    const int64_t plane = (int64_t)H * W, oplane = (int64_t)oh * ow;
+    const T *go = gout + (int64_t)b * Dd * Dd * oplane;
     const T *a = in1 + ((int64_t)b * C + c) * plane;
     const T *bb = in2 + ((int64_t)b * C + c) * plane;
-    float s1acc = 0.f, s2acc = 0.f;
+    float acc1 = 0.f, acc2 = 0.f;
     for (int tj = -drad; tj <= drad; ++tj) {
         for (int ti = -drad; ti <= drad; ++ti) {
-            const int tc = (tj + drad) * Dd + (ti + drad);
+            const T *gc = go + (int64_t)((tj + drad) * Dd + (ti + drad)) * oplane;
             const int dy = tj * s2, dx = ti * s2;
-            // d in1[y,x] += gout[tc,y,x] * in2[y+dy,x+dx]
-            const int yb = y + dy, xb = x + dx;
-            if (yb >= 0 && yb < H && xb >= 0 && xb < W)
-                s1acc = fmaf(to_f32<T>(go[tc * plane + (int64_t)y * W + x]), to_f32<T>(bb[(int64_t)yb * W + xb]), s1acc);
-            // d in2[y,x] += gout[tc,y-dy,x-dx] * in1[y-dy,x-dx]
-            const int ya = y - dy, xa = x - dx;
-            if (ya >= 0 && ya < H && xa >= 0 && xa < W)
-                s2acc = fmaf(to_f32<T>(go[tc * plane + (int64_t)ya * W + xa]), to_f32<T>(a[(int64_t)ya * W + xa]), s2acc);
+            for (int j = -krad; j <= krad; ++j) {
+                for (int i = -krad; i <= krad; ++i) {
+                    {   // this element as in1[.., ya = y, xa = x]
+                        const int ny = y - j - max_disp + pad, nx = x - i - max_disp + pad;
+                        const int yb = y + dy, xb = x + dx;
+                        if (ny >= 0 && nx >= 0 && ny % s1 == 0 && nx % s1 == 0 && ny / s1 < oh && nx / s1 < ow &&
+                            yb >= 0 && yb < H && xb >= 0 && xb < W)
+                            acc1 = fmaf(to_f32<T>(gc[(int64_t)(ny / s1) * ow + nx / s1]), to_f32<T>(bb[(int64_t)yb * W + xb]), acc1);
+                    }
+                    {   // this element as in2[.., yb = y, xb = x]
+                        const int ny = y - dy - j - max_disp + pad, nx = x - dx - i - max_disp + pad;
+                        const int ya = y - dy, xa = x - dx;
+                        if (ny >= 0 && nx >= 0 && ny % s1 == 0 && nx % s1 == 0 && ny / s1 < oh && nx / s1 < ow &&
+                            ya >= 0 && ya < H && xa >= 0 && xa < W)
+                            acc2 = fmaf(to_f32<T>(gc[(int64_t)(ny / s1) * ow + nx / s1]), to_f32<T>(a[(int64_t)ya * W + xa]), acc2);
+                    }
+                }
+            }
         }
     }
-    g1[idx] = from_f32<T>(s1acc * scale);
-    g2[idx] = from_f32<T>(s2acc * scale);
+    g1[idx] = from_f32<T>(acc1 * scale);
+    g2[idx] = from_f32<T>(acc2 * scale);
+}
+
+// PWC-Net's configuration (pad 4, kernel 1, max displacement 4, strides 1), fp32: tiled like the forward.  One thread owns one
+// pixel of an 8 x 32 tile and keeps its 81 + 81 gradient-of-output values in registers -- g1[d] = gout[d, p] for d in1 and
+// g2[d] = gout[d, p - d] for d in2, loaded once -- while the input maps stream through LDS in chunks of 8 channels WITH their
+// +-4 halos (coalesced 16-byte row loads, zero outside the image); per channel the thread does 2 x 81 fma on conflict-free
+// ds_read_b32 (consecutive lanes = consecutive columns).  HBM traffic = the algorithmic (4*C + 81) * H * W * 4 bytes plus the
+// 2.5x halo re-reads, which hit in L2.
+constexpr int kBwdCK = 8;
+__global__ void __launch_bounds__(256)
+corr81_bwd_kernel(const float *__restrict__ in1, const float *__restrict__ in2, const float *__restrict__ gout,
+                  float *__restrict__ g1o, float *__restrict__ g2o, int C, int H, int W, int tiles_x, int tiles_y, float scale) {
+    __shared__ __attribute__((aligned(16))) float s1[kBwdCK][kS2Rows][kPitch];     // in1 halo tile
+    __shared__ __attribute__((aligned(16))) float s2[kBwdCK][kS2Rows][kPitch];     // in2 halo tile
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * kTW, y0 = ty * kTH;
+    const int px = tid & 31, py = tid >> 5;
+    const int x = x0 + px, y = y0 + py;
+    const bool inside = (x < W) && (y < H);
+    const int64_t plane = (int64_t)H * W;
+    const float *go = gout + (int64_t)b * 81 * plane;
+    float ga[81], gb[81];
+#pragma unroll
+    for (int d = 0; d < 81; ++d) {
+        const int dy = d / 9 - kD, dx = d % 9 - kD;
+        ga[d] = inside ? go[(int64_t)d * plane + (int64_t)y * W + x] : 0.f;
+        const int yy = y - dy, xx = x - dx;
+        gb[d] = (inside && yy >= 0 && yy < H && xx >= 0 && xx < W) ? go[(int64_t)d * plane + (int64_t)yy * W + xx] : 0.f;
+    }
+    const float *p1 = in1 + (int64_t)b * C * plane;
+    const float *p2 = in2 + (int64_t)b * C * plane;
+    const bool vec = (W % 4 == 0);
+    for (int c0 = 0; c0 < C; c0 += kBwdCK) {
+        if (c0) __syncthreads();
+        // stage both halo tiles: kBwdCK x 16 rows x 10 quads each
+        for (int i = tid; i < 2 * kBwdCK * kS2Rows * kS2Quads; i += 256) {
+            const int which = i / (kBwdCK * kS2Rows * kS2Quads);
+            const int rem = i % (kBwdCK * kS2Rows * kS2Quads);
+            const int c = rem / (kS2Rows * kS2Quads);
+            const int row = (rem / kS2Quads) % kS2Rows;
+            const int q = rem % kS2Quads;
+            const int yy = y0 + row - kD;
+            const bool ok = (c0 + c < C) && (yy >= 0) && (yy < H);
+            const float *src = (which ? p2 : p1) + (int64_t)(c0 + c) * plane + (int64_t)yy * W;
+            const float4 v = load_quad<float>(src, x0 + 4 * q - kD, W, ok, vec);
+            *reinterpret_cast<float4 *>(which ? &s2[c][row][4 * q] : &s1[c][row][4 * q]) = v;
+        }
+        __syncthreads();
+        const int cn = min(kBwdCK, C - c0);
+        for (int c = 0; c < cn; ++c) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < 81; ++d) {
+                const int dyi = d / 9, dxi = d % 9;
+                a1 = fmaf(ga[d], s2[c][py + dyi][px + dxi], a1);                 // in2[c, p + d]
+                a2 = fmaf(gb[d], s1[c][py + 8 - dyi][px + 8 - dxi], a2);         // in1[c, p - d]
+            }
+            if (inside) {
+                const int64_t o = ((int64_t)b * C + c0 + c) * plane + (int64_t)y * W + x;
+                g1o[o] = a1 * scale;
+                g2o[o] = a2 * scale;
+            }
+        }
+    }
 }
 
 template <typename T>
@@ -575,25 +664,40 @@ extern "C" int pwc_corr_bwd(const void *in1, const void *in2, const void *grad_o
                             float corr_multiply, int dtype, unsigned flags, void *stream) {
     if (!in1 || !in2 || !grad_out || !grad_in1 || !grad_in2) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: null pointer");
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: bad shape");
-    if (kernel_size != 1 || stride1 != 1 || pad_size != max_disp || stride2 < 1)
-        PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr_bwd: only kernel_size=1, stride1=1, pad_size=max_disp (got k=%d s1=%d pad=%d d=%d)",
-                 kernel_size, stride1, pad_size, max_disp);
-    const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
+    if (kernel_size < 1 || (kernel_size & 1) == 0 || max_disp < 0 || stride1 < 1 || stride2 < 1 || pad_size < 0)
+        PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: bad parameters pad=%d k=%d d=%d s1=%d s2=%d", pad_size, kernel_size, max_disp,
+                 stride1, stride2);
+    const int krad = (kernel_size - 1) / 2;
     const int drad = max_disp / stride2;
+    const int border = krad + max_disp;
+    const int oh = (H + 2 * pad_size - 2 * border + stride1 - 1) / stride1;
+    const int ow = (W + 2 * pad_size - 2 * border + stride1 - 1) / stride1;
+    if (oh <= 0 || ow <= 0) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: empty output (%d x %d)", oh, ow);
+    const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)(kernel_size * kernel_size * C) : corr_multiply;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == PWC_F32 && kernel_size == 1 && max_disp == kD && pad_size == kD && stride1 == 1 && stride2 == 1 &&
+        !((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15u)) {
+        const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kTH - 1) / kTH;
+        const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+        if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: grid too large");
+        hipLaunchKernelGGL(corr81_bwd_kernel, dim3((unsigned)nblk), dim3(256), 0, st,
+                           (const float *)in1, (const float *)in2, (const float *)grad_out, (float *)grad_in1,
+                           (float *)grad_in2, C, H, W, tiles_x, tiles_y, scale);
+        return pwc::check_launch("corr81_bwd_kernel");
+    }
     const int64_t total = (int64_t)B * C * H * W;
     const int64_t nblk = (total + 255) / 256;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_corr_bwd: grid too large");
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == PWC_F32) {
-        hipLaunchKernelGGL((corr_bwd_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st,
+        hipLaunchKernelGGL((corr_bwd_generic_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, st,
                            (const float *)in1, (const float *)in2, (const float *)grad_out, (float *)grad_in1,
-                           (float *)grad_in2, C, H, W, drad, stride2, total, scale);
+                           (float *)grad_in2, C, H, W, oh, ow, pad_size, krad, max_disp, stride1, stride2, drad, total, scale);
     } else if (dtype == PWC_F16) {
-        hipLaunchKernelGGL((corr_bwd_kernel<__half>), dim3((unsigned)nblk), dim3(256), 0, st,
+        hipLaunchKernelGGL((corr_bwd_generic_kernel<__half>), dim3((unsigned)nblk), dim3(256), 0, st,
                            (const __half *)in1, (const __half *)in2, (const __half *)grad_out, (__half *)grad_in1,
-                           (__half *)grad_in2, C, H, W, drad, stride2, total, scale);
+                           (__half *)grad_in2, C, H, W, oh, ow, pad_size, krad, max_disp, stride1, stride2, drad, total, scale);
     } else {
         PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr_bwd: dtype %d", dtype);
     }
-    return pwc::check_launch("corr_bwd_kernel");
+    return pwc::check_launch("corr_bwd_generic_kernel");
 }

@@ -148,15 +148,48 @@ int launch_warp(const void *x, const void *flo, void *out, int B, int C, int H, 
 }
 
 // ---- backward --------------------------------------------------------------------------------------------
-// d out / d x  : scatter of mask * bilinear weight * grad_out to the four taps (atomicAdd; like torch's
-//                grid_sample backward the summation order is not fixed);
+// d out / d x  : scatter of mask * bilinear weight * grad_out to the four taps.  Which output pixels sample a given source
+//                pixel depends on the flow, so a gather form would need a search window as large as the largest flow; the
+//                scatter is made DETERMINISTIC instead: with a caller-provided workspace the contributions are accumulated
+//                as 64-bit fixed-point integers (integer addition is associative, so the atomics' arrival order does not
+//                matter), scaled so that the largest |grad_out| sits 40 bits above the unit in the last place (fp32 has
+//                24), and converted to float once at the end.  Without a workspace: float atomicAdd, like torch's
+//                grid_sample backward (summation order not fixed);
 // d out / d flo: mask * sum_c grad_out * (d sample / d ix, d sample / d iy) * d(ix,iy)/d(u,v), where
 //                d ix / d u = flow_scale * W / max(W-1,1)        (align_corners = 0)
 //                           = flow_scale * (W-1) / max(W-1,1)    (align_corners = 1).
 // The mask is a constant: the reference thresholds it in place (PWCNet.py:174-175), which cuts its graph.
+// largest |grad_out| as float bits (order-independent: max), into *out (zeroed before)
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float *__restrict__ v, int64_t n, unsigned *out) {
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = fabsf(v[i]);
+        if (a == a && a < __builtin_huge_valf()) m = max(m, __float_as_uint(a));     // finite values only
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// fixed-point scale for a tensor whose largest magnitude has float bits `mbits`: 2^(40 - exponent)
+__device__ __forceinline__ float fixed_scale(unsigned mbits) {
+    const int e = (int)(mbits >> 23) - 127;                  // floor(log2(max)); -127 for zero / subnormal
+    return __uint_as_float((unsigned)(min(max(40 - e, -126), 127) + 127) << 23);
+}
+
+__global__ void __launch_bounds__(256)
+fixed_to_float_kernel(const long long *__restrict__ acc, const unsigned *__restrict__ mbits, float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (float)((double)acc[i] / (double)fixed_scale(*mbits));
+}
+
+template <bool FIXED>
 __global__ void __launch_bounds__(kWarpThreads)
 warp_bwd_kernel(const float *__restrict__ x, const float *__restrict__ flo, const float *__restrict__ go,
-                float *__restrict__ gx, float *__restrict__ gflo, int C, int H, int W, int64_t npix,
+                float *__restrict__ gx, long long *__restrict__ gacc, const unsigned *__restrict__ mbits,
+                float *__restrict__ gflo, int C, int H, int W, int64_t npix,
                 float flow_scale, int align_corners, float thr) {
     const int64_t i = (int64_t)blockIdx.x * kWarpThreads + threadIdx.x;
     if (i >= npix) return;
@@ -201,19 +234,32 @@ warp_bwd_kernel(const float *__restrict__ x, const float *__restrict__ flo, cons
     const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
     const int o00 = yc0 * W + xc0, o01 = yc0 * W + xc1, o10 = yc1 * W + xc0, o11 = yc1 * W + xc1;
     const float *xb = x + (int64_t)b * C * plane;
-    float *gxb = gx + (int64_t)b * C * plane;
+    const int64_t gbase = (int64_t)b * C * plane;
     const float *gob = go + (int64_t)b * C * plane + pix;
+    float fscale = 0.f;
+    if constexpr (FIXED) fscale = fixed_scale(*mbits);
     float dix = 0.f, diy = 0.f;
-    for (int c = 0; c < C; ++c, xb += plane, gxb += plane, gob += plane) {
+    for (int c = 0; c < C; ++c, xb += plane, gob += plane) {
         const float g = gob[0];
         const float s00 = v00 ? xb[o00] : 0.f, s01 = v01 ? xb[o01] : 0.f;
         const float s10 = v10 ? xb[o10] : 0.f, s11 = v11 ? xb[o11] : 0.f;
         dix += g * (ay0 * (s01 - s00) + ay1 * (s11 - s10));
         diy += g * (ax0 * (s10 - s00) + ax1 * (s11 - s01));
-        if (w00 != 0.f) atomicAdd(gxb + o00, g * w00);
-        if (w01 != 0.f) atomicAdd(gxb + o01, g * w01);
-        if (w10 != 0.f) atomicAdd(gxb + o10, g * w10);
-        if (w11 != 0.f) atomicAdd(gxb + o11, g * w11);
+        const int64_t cb = gbase + (int64_t)c * plane;
+        if constexpr (FIXED) {
+            // round(g * w * 2^k) as int64: deterministic per contribution, associative in the sum
+            unsigned long long *a = reinterpret_cast<unsigned long long *>(gacc) + cb;
+            if (w00 != 0.f) atomicAdd(a + o00, (unsigned long long)__double2ll_rn((double)(g * w00) * (double)fscale));
+            if (w01 != 0.f) atomicAdd(a + o01, (unsigned long long)__double2ll_rn((double)(g * w01) * (double)fscale));
+            if (w10 != 0.f) atomicAdd(a + o10, (unsigned long long)__double2ll_rn((double)(g * w10) * (double)fscale));
+            if (w11 != 0.f) atomicAdd(a + o11, (unsigned long long)__double2ll_rn((double)(g * w11) * (double)fscale));
+        } else {
+            float *gxb = gx + cb;
+            if (w00 != 0.f) atomicAdd(gxb + o00, g * w00);
+            if (w01 != 0.f) atomicAdd(gxb + o01, g * w01);
+            if (w10 != 0.f) atomicAdd(gxb + o10, g * w10);
+            if (w11 != 0.f) atomicAdd(gxb + o11, g * w11);
+        }
     }
     const float sx = align_corners ? (float)(W - 1) / (float)max(W - 1, 1) : (float)W / (float)max(W - 1, 1);
     const float sy = align_corners ? (float)(H - 1) / (float)max(H - 1, 1) : (float)H / (float)max(H - 1, 1);
@@ -223,22 +269,46 @@ warp_bwd_kernel(const float *__restrict__ x, const float *__restrict__ flo, cons
 
 }  // namespace
 
+extern "C" int64_t pwc_warp_bwd_workspace_bytes(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return -1;
+    return (int64_t)B * C * H * W * 8 + 16;                     // int64 accumulators + the |grad_out| maximum
+}
+
 extern "C" int pwc_warp_bwd(const void *x, const void *flo, const void *grad_out, void *grad_x, void *grad_flo,
                             int B, int C, int H, int W,
-                            float flow_scale, int align_corners, float mask_threshold, int dtype, void *stream) {
+                            float flow_scale, int align_corners, float mask_threshold, int dtype,
+                            void *workspace, int64_t workspace_bytes, void *stream) {
     if (!x || !flo || !grad_out || !grad_x || !grad_flo) PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: null pointer");
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: bad shape %dx%dx%dx%d", B, C, H, W);
     if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_warp_bwd: dtype %d (f32 only)", dtype);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t npix = (int64_t)B * H * W;
+    const int64_t nel = npix * C;
     const int64_t nblk = (npix + kWarpThreads - 1) / kWarpThreads;
-    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: grid too large");
-    hipError_t e = hipMemsetAsync(grad_x, 0, (size_t)npix * C * sizeof(float), st);
+    if (nblk > 0x7fffffffLL || (nel + 255) / 256 > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: grid too large");
+    const float *xf = static_cast<const float *>(x), *ff = static_cast<const float *>(flo), *gf = static_cast<const float *>(grad_out);
+    if (workspace) {
+        // deterministic path: 64-bit fixed-point accumulation in the caller's workspace
+        if (workspace_bytes < pwc_warp_bwd_workspace_bytes(B, C, H, W) || (reinterpret_cast<uintptr_t>(workspace) & 7u))
+            PWC_FAIL(PWC_EINVAL, "pwc_warp_bwd: workspace needs %lld bytes, 8-byte aligned", (long long)pwc_warp_bwd_workspace_bytes(B, C, H, W));
+        long long *acc = static_cast<long long *>(workspace);
+        unsigned *mbits = reinterpret_cast<unsigned *>(acc + nel);
+        hipError_t e = hipMemsetAsync(workspace, 0, (size_t)nel * 8 + 16, st);
+        if (e != hipSuccess) { pwc::set_error("pwc_warp_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        const int mblk = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)mblk), dim3(256), 0, st, gf, nel, mbits);
+        hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3((unsigned)nblk), dim3(kWarpThreads), 0, st, xf, ff, gf,
+                           static_cast<float *>(nullptr), acc, mbits, static_cast<float *>(grad_flo), C, H, W, npix,
+                           flow_scale, align_corners, mask_threshold);
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, acc, mbits,
+                           static_cast<float *>(grad_x), nel);
+        return pwc::check_launch("warp_bwd_kernel<fixed>");
+    }
+    hipError_t e = hipMemsetAsync(grad_x, 0, (size_t)nel * sizeof(float), st);
     if (e != hipSuccess) { pwc::set_error("pwc_warp_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL(warp_bwd_kernel, dim3((unsigned)nblk), dim3(kWarpThreads), 0, st,
-                       static_cast<const float *>(x), static_cast<const float *>(flo), static_cast<const float *>(grad_out),
-                       static_cast<float *>(grad_x), static_cast<float *>(grad_flo), C, H, W, npix,
-                       flow_scale, align_corners, mask_threshold);
+    hipLaunchKernelGGL(warp_bwd_kernel<false>, dim3((unsigned)nblk), dim3(kWarpThreads), 0, st, xf, ff, gf,
+                       static_cast<float *>(grad_x), static_cast<long long *>(nullptr), static_cast<const unsigned *>(nullptr),
+                       static_cast<float *>(grad_flo), C, H, W, npix, flow_scale, align_corners, mask_threshold);
     return pwc::check_launch("warp_bwd_kernel");
 }
 

@@ -139,8 +139,9 @@ def warp(x: torch.Tensor, flo: torch.Tensor, flow_scale: float = 1.0, align_corn
 
 
 def warp_backward(x: torch.Tensor, flo: torch.Tensor, grad_out: torch.Tensor, flow_scale: float = 1.0,
-                  align_corners: bool = False, mask_threshold: float = 0.9999):
-    """(grad_x, grad_flo) of `warp` for contiguous float32 tensors."""
+                  align_corners: bool = False, mask_threshold: float = 0.9999, deterministic: bool = True):
+    """(grad_x, grad_flo) of `warp` for contiguous float32 tensors.  deterministic (default): the scatter into grad_x
+    accumulates 64-bit fixed-point integers in a scratch buffer (bit-reproducible); False: float atomics."""
     lib = _lib.load()
     for name, t in (("x", x), ("flo", flo), ("grad_out", grad_out)):
         _plane_dense(t, name)
@@ -151,10 +152,14 @@ def warp_backward(x: torch.Tensor, flo: torch.Tensor, grad_out: torch.Tensor, fl
         raise ValueError("flo must be %s and grad_out %s" % ((B, 2, H, W), (B, C, H, W)))
     gx = torch.empty_like(x)
     gf = torch.empty_like(flo)
+    ws, ws_bytes = None, 0
+    if deterministic:
+        ws_bytes = lib.pwc_warp_bwd_workspace_bytes(B, C, H, W)
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=x.device)
     with torch.cuda.device(x.device):
         rc = lib.pwc_warp_bwd(x.data_ptr(), flo.data_ptr(), grad_out.data_ptr(), gx.data_ptr(), gf.data_ptr(),
                               B, C, H, W, float(flow_scale), 1 if align_corners else 0, float(mask_threshold),
-                              _dtype_code(x), _stream(x))
+                              _dtype_code(x), ws.data_ptr() if ws is not None else None, ws_bytes, _stream(x))
     check(rc, "pwc_warp_bwd")
     return gx, gf
 

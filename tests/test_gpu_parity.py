@@ -102,6 +102,77 @@ def test_corr_backward_matches_autograd_of_oracle(dev):
     assert torch.allclose(g2.cpu(), b.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 13, 20, 45), (1, 32, 24, 64), (3, 5, 7, 9)])
+def test_corr_backward_tiled_pwc_config(dev, shape):
+    """corr81_bwd_kernel (PWC-Net's pad 4 / k 1 / d 4 / strides 1, fp32: LDS-tiled gather) vs autograd through the oracle:
+    ragged tiles, widths that are not multiples of 4, both scale modes; bit-reproducible (no atomics)."""
+    from opticalflow_amd import ops
+    B, C, H, W = shape
+    a = seeded_rand(shape, 23, -1, 1).requires_grad_(True)
+    b = seeded_rand(shape, 24, -1, 1).requires_grad_(True)
+    go = seeded_rand((B, 81, H, W), 25, -1, 1)
+    O.correlation(a, b, 4, 1, 4, 1, 1, 1).backward(go)
+    ad, bd, god = a.detach().to(dev), b.detach().to(dev), go.to(dev)
+    g1, g2 = ops.correlation_backward(ad, bd, god)
+    assert torch.allclose(g1.cpu(), a.grad, rtol=1e-4, atol=2e-5) and torch.allclose(g2.cpu(), b.grad, rtol=1e-4, atol=2e-5)
+    h1, h2 = ops.correlation_backward(ad, bd, god)
+    assert torch.equal(g1, h1) and torch.equal(g2, h2)
+    n1, n2 = ops.correlation_backward(ad, bd, god, normalize=True)
+    assert torch.allclose(n1.cpu(), a.grad / C, rtol=1e-4, atol=2e-5) and torch.allclose(n2.cpu(), b.grad / C, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("cfg", [(3, 3, 6, 2, 2), (20, 3, 20, 1, 2), (2, 1, 2, 1, 1), (4, 1, 4, 2, 1), (1, 3, 4, 1, 2), (0, 1, 2, 1, 2)])
+def test_corr_backward_general_configs(dev, cfg):
+    """pwc_corr_bwd accepts any (pad, kernel_size, max_displacement, stride1, stride2) like the reference's backward
+    (correlation_cuda_kernel.cu:150-334); checked against autograd through the oracle's general correlation, fp32 and fp16."""
+    from opticalflow_amd import ops
+    pad, k, d, s1, s2 = cfg
+    C, H, W = 4, 15 + 2 * max(0, (k - 1) // 2 + d - pad), 17 + 2 * max(0, (k - 1) // 2 + d - pad)
+    nch, oh, ow = O.corr_output_shape(C, H, W, pad, k, d, s1, s2)
+    a = seeded_rand((2, C, H, W), 26, -1, 1).requires_grad_(True)
+    b = seeded_rand((2, C, H, W), 27, -1, 1).requires_grad_(True)
+    go = seeded_rand((2, nch, oh, ow), 28, -1, 1)
+    O.correlation(a, b, pad, k, d, s1, s2, 1.5).backward(go)
+    g1, g2 = ops.correlation_backward(a.detach().to(dev), b.detach().to(dev), go.to(dev), pad, k, d, s1, s2, 1.5)
+    assert torch.allclose(g1.cpu(), a.grad, rtol=1e-4, atol=2e-5) and torch.allclose(g2.cpu(), b.grad, rtol=1e-4, atol=2e-5)
+    h1, h2 = ops.correlation_backward(a.detach().half().to(dev), b.detach().half().to(dev), go.half().to(dev), pad, k, d, s1, s2, 1.5)
+    assert h1.dtype == torch.float16
+    assert (h1.float().cpu() - a.grad).abs().max().item() <= 2e-2 * max(1.0, a.grad.abs().max().item())
+    assert (h2.float().cpu() - b.grad).abs().max().item() <= 2e-2 * max(1.0, b.grad.abs().max().item())
+    # the forward of the same configuration, for completeness of the pair
+    y = ops.correlation(a.detach().to(dev), b.detach().to(dev), pad, k, d, s1, s2, 1.5)
+    with torch.no_grad():
+        assert torch.allclose(y.cpu(), O.correlation(a, b, pad, k, d, s1, s2, 1.5), rtol=1e-4, atol=1e-5)
+
+
+def test_warp_backward_deterministic_fixed_point(dev):
+    """pwc_warp_bwd with a workspace accumulates the scatter into grad_x as 64-bit fixed-point integers: bit-identical run
+    after run (float atomics are not), equal to the float-atomic path and to autograd through the oracle within fp32
+    rounding; convergent flows (many output pixels sampling the same source pixel) stress the accumulation."""
+    from opticalflow_amd import ops
+    B, C, H, W = 2, 6, 24, 40
+    x = seeded_rand((B, C, H, W), 60, -1, 1)
+    flo = seeded_rand((B, 2, H, W), 61, -3, 3)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flo[1, 0] = (W / 2 - xx) * 0.9 + 0.3                    # image 1: everything samples near the centre column / row
+    flo[1, 1] = (H / 2 - yy) * 0.9 + 0.2
+    go = seeded_rand((B, C, H, W), 62, -100, 100)
+    xd, fd, gd = x.to(dev), flo.to(dev), go.to(dev)
+    gx, gf = ops.warp_backward(xd, fd, gd, 1.25, False, 0.9999)
+    for _ in range(5):
+        gx2, gf2 = ops.warp_backward(xd, fd, gd, 1.25, False, 0.9999)
+        assert torch.equal(gx, gx2) and torch.equal(gf, gf2)
+    ax, af = ops.warp_backward(xd, fd, gd, 1.25, False, 0.9999, deterministic=False)
+    assert torch.equal(af, gf)
+    assert (ax - gx).abs().max().item() <= 1e-5 * max(1.0, gx.abs().max().item())
+    xr, fr = x.clone().requires_grad_(True), flo.clone().requires_grad_(True)
+    O.warp(xr, fr * 1.25).backward(go)
+    assert (gx.cpu() - xr.grad).abs().max().item() <= 1e-5 * max(1.0, xr.grad.abs().max().item())
+    assert (gf.cpu() - fr.grad).abs().max().item() <= 1e-4 * max(1.0, fr.grad.abs().max().item())
+    z, _ = ops.warp_backward(xd, fd, torch.zeros_like(gd), 1.25, False, 0.9999)          # all-zero grad_out: scale degenerates safely
+    assert (z == 0).all()
+
+
 def test_correlation_module_and_pybind_shim(dev):
     import correlation_cuda
     from opticalflow_amd import Correlation
