@@ -76,6 +76,17 @@ int pwc_corr_fwd(const void *in1, const void *in2, void *out,
                  int64_t in1_bstride, int64_t in2_bstride, int64_t out_bstride,
                  void *stream);
 
+/* warp + cost volume in one kernel for the decoder levels below the coarsest (PWCNet.py:212-213, 226-227, 240-241, 256-257:
+ * corr = self.corr(c1, self.warp(c2, up_flow * s)); the warped tensor has no other consumer):
+ *   out[b, (dy+4)*9 + (dx+4), y, x] = scale * sum_c in1[b,c,y,x] * warp(x2, flow_scale * flo)[b,c,y+dy,x+dx]   (+ LeakyReLU)
+ * with pwc_warp_fwd's sampling / mask rule and pwc_corr_fwd's PWC configuration (pad 4, kernel 1, max displacement 4, strides 1);
+ * bit-identical to pwc_warp_fwd followed by pwc_corr_fwd.  f32 only.  Returns PWC_EUNSUPPORTED (nothing launched) unless
+ * W % 4 == 0 and in1 / x2 / out are 16-byte aligned: call the two separate entry points then. */
+int pwc_warp_corr81_fwd(const void *in1, const void *x2, const void *flo, void *out, int B, int C, int H, int W,
+                        float flow_scale, int align_corners, float mask_threshold,
+                        float corr_multiply, unsigned flags, float leaky_slope,
+                        int64_t in1_bstride, int64_t x2_bstride, int64_t flo_bstride, int64_t out_bstride, void *stream);
+
 /* Gradients of pwc_corr_fwd w.r.t. in1 and in2 (no fused activation; same scale rule as forward), for ANY
  * (pad_size, kernel_size, max_disp, stride1, stride2) like the reference's backward (correlation_cuda_kernel.cu:150-334);
  * grad_out: [B, D*D, outH, outW] contiguous, in*, grad_in*: [B,C,H,W] contiguous.  Gather form with a fixed summation

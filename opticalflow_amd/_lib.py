@@ -29,6 +29,8 @@ SIGNATURES = {
     "pwc_corr_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_float,
                              c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_warp_corr81_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_float,
+                                    c_float, c_uint, c_float, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "pwc_corr_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_void_p]),
     "pwc_warp_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

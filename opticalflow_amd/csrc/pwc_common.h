@@ -73,6 +73,14 @@ __device__ __forceinline__ v4i32 make_rsrc(const void *base, int num_bytes) {
     return r;
 }
 
+// wave-uniform pointer the compiler can PROVE uniform (otherwise every buffer op is wrapped in a waterfall loop)
+__device__ __forceinline__ void *uniform_ptr(const void *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }

@@ -22,7 +22,10 @@
 //     live inside the decoder's concat arena).
 // Generic path (any pad/kernel/stride): one thread per output element, used only by callers
 // other than PWCDCNet.
+#include <stdlib.h>
+
 #include "pwc_common.h"
+#include "pwc_warp_taps.h"
 
 // Cache policy (profiles/r01_corr_ablation.md): the 81-channel output is written once and not read again by this
 // kernel -> non-temporal stores (64.8 -> 59.8 us at level 2, batch 16; whole forward unchanged).  The inputs are NOT
@@ -234,6 +237,25 @@ constexpr int kBufFloats = kS2Floats + kS1Floats;         // 3840 floats = 15 Ki
 constexpr unsigned kOOBv = 0x80000000u;
 constexpr int kLoaderWave = kND;                          // wave 9 (a second loader wave measured slower: 72 vs 65 us)
 constexpr int kThreadsDma = 64 * (kND + 1);               // 640
+// Fused warp + correlation (PWCNet.py:212-213, 226-227, 240-241, 256-257: warp(c2, up_flow*s) is consumed by the correlation
+// only): five more waves per workgroup PRODUCE the in2 halo tile of every chunk -- each lane owns two of the 640 halo pixels,
+// computes their sample taps once per tile and per chunk gathers 2 x 8 bytes per channel, blends and writes the warped value
+// into the ring slot with ds_write -- while the loader wave keeps streaming in1 by LDS-DMA and the nine fma waves run
+// unchanged.  The warped tensor never exists in HBM (one write + one read of c2 per level less) and the sample taps are
+// computed 2.5x per pixel (halo) instead of once per 8-channel block of every pixel.
+#ifndef PWC_WARPCORR_WPE
+#define PWC_WARPCORR_WPE 8          // waves per SIMD the fused kernel's register budget must allow (8: two workgroups per CU)
+#endif
+constexpr int kProducers = 5;
+constexpr int kThreadsWarp = 64 * (kND + 1 + kProducers);  // 960
+static_assert(kProducers * 64 * 2 == kS2Rows * 40, "two halo pixels per producer lane");
+
+struct WarpArgs {
+    const float *flo;          // [B,2,H,W] (u, v); nullptr = plain correlation
+    int64_t bsf;
+    float flow_scale, thr;
+    int align_corners;
+};
 #ifndef PWC_CORR_PER_CU
 #define PWC_CORR_PER_CU 2
 #endif
@@ -275,22 +297,27 @@ __device__ __forceinline__ void corr_offsets(unsigned (&off)[kDmaInstr], int lan
     }
 }
 
+template <bool WARP>
 __device__ __forceinline__ void corr_issue(const float *p1, const float *p2, int c0, int C, int plane, float *buf,
                                            const unsigned (&off)[kDmaInstr]) {
     const int nbytes = min(kCKd, C - c0) * plane * 4;
     const pwc::v4i32 r2 = pwc::make_rsrc(p2 + (int64_t)c0 * plane, nbytes);
     const pwc::v4i32 r1 = pwc::make_rsrc(p1 + (int64_t)c0 * plane, nbytes);
     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
+    if constexpr (!WARP) {                      // fused kernel: the in2 tile is produced by the warp waves
 #pragma unroll
-    for (int k = 0; k < kS2Instr; ++k) PWC_CORR_DMA(r2, base + k * 1024, off[k]);
+        for (int k = 0; k < kS2Instr; ++k) PWC_CORR_DMA(r2, base + k * 1024, off[k]);
+    }
 #pragma unroll
     for (int k = kS2Instr; k < kDmaInstr; ++k) PWC_CORR_DMA(r1, base + k * 1024, off[k]);
 }
 
-__global__ void __launch_bounds__(kThreadsDma)
+// (fused: 2 workgroups x 15 waves per CU = 7.5 per SIMD -> at most 64 registers)
+template <bool WARP>
+__global__ void __launch_bounds__(WARP ? kThreadsWarp : kThreadsDma, WARP ? PWC_WARPCORR_WPE : 1)
 corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, float *__restrict__ out,
                   int C, int H, int W, int tiles_x, int tiles_y, int nblk,
-                  int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky) {
+                  int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky, WarpArgs wa) {
     __shared__ __attribute__((aligned(16))) float smem[kRing * kBufFloats];
 
     const int tid = threadIdx.x;
@@ -319,7 +346,7 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
                 ip1 = in1 + (int64_t)t.b * bs1;
                 ip2 = in2 + (int64_t)t.b * bs2;
             }
-            corr_issue(ip1, ip2, is_chunk * kCKd, C, plane, smem + (is_step % kRing) * kBufFloats, off);
+            corr_issue<WARP>(ip1, ip2, is_chunk * kCKd, C, plane, smem + (is_step % kRing) * kBufFloats, off);
             ++is_step;
             if (++is_chunk == nchunks) { is_chunk = 0; is_tile += stride; }
         };
@@ -328,13 +355,81 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
         for (int s = 0; s < nsteps; ++s) {
             // chunk s has landed; the chunks issued after it (up to kRing-2 of them) may stay in flight
             const int ahead = min(kRing - 2, nsteps - 1 - s);
-            if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kDmaInstr) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kDmaInstr) : "memory");
+            constexpr int kI = WARP ? kS1Instr : kDmaInstr;        // LDS-DMA instructions this wave issues per chunk
+            if (ahead >= 2)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kI) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kI) : "memory");
             else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // B_s: consumers may read slot s%R; they have finished slot (s-1)%R
             issue_next();                      // chunk s+R-1 -> slot (s-1)%R
         }
         return;
+    }
+
+    if constexpr (WARP) {
+        if (wave > kLoaderWave) {
+            // ================= warp producers: chunk s+2 is written while the fma waves consume chunk s ===========
+            const int pw = wave - (kLoaderWave + 1);
+            // (A variant that software-pipelined the two halo pixels of a lane as half-chunks -- one half's gathers in flight
+            // while the other is blended -- measured SLOWER, 131 vs 119 us at level 2: the producers are bound by instruction
+            // issue next to nine fma waves, not by gather latency; they have two ring steps of slack per chunk anyway.)
+            int ldsoff[2], otop[2], obot[2];
+            float wgt[2][4];
+            const float *src = nullptr;
+            int pr_tile = blockIdx.x, pr_chunk = 0, pr_step = 0;
+            auto produce = [&]() {
+                if (pr_step >= nsteps) return;
+                if (pr_chunk == 0) {
+                    const TileXY t = tile_of(pr_tile, nblk, tiles_x, tiles_y);
+                    const float *fu = wa.flo + (int64_t)t.b * wa.bsf;
+                    src = in2 + (int64_t)t.b * bs2;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int hp = (pw * 2 + k) * 64 + lane;              // consecutive lanes = consecutive halo columns
+                        const int row = hp / 40, col = hp - row * 40;
+                        const int gy = t.y0 - kD + row, gx = t.x0 - kD + col;
+                        const bool inimg = (gy >= 0) && (gy < H) && (gx >= 0) && (gx < W);
+                        const int gyc = min(max(gy, 0), H - 1), gxc = min(max(gx, 0), W - 1);
+                        const float u = fu[(int64_t)gyc * W + gxc] * wa.flow_scale;
+                        const float v = fu[(int64_t)plane + (int64_t)gyc * W + gxc] * wa.flow_scale;
+                        const pwc_warp::PairTaps pt = pwc_warp::make_pair_taps((float)gx + u, (float)gy + v, H, W, wa.align_corners, wa.thr);
+                        otop[k] = pt.otop * 4;
+                        obot[k] = pt.obot * 4;
+                        // a halo pixel outside the image is the correlation's zero padding: all four weights zero
+                        wgt[k][0] = inimg ? pt.wa : 0.f; wgt[k][1] = inimg ? pt.wb : 0.f;
+                        wgt[k][2] = inimg ? pt.wc : 0.f; wgt[k][3] = inimg ? pt.wd : 0.f;
+                        ldsoff[k] = row * kPitch + col;
+                    }
+                }
+                const int c0 = pr_chunk * kCKd;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    pwc::uniform_ptr(src + (int64_t)c0 * plane), 0, __builtin_amdgcn_readfirstlane(min(kCKd, C - c0) * plane * 4), 0x00020000);
+                float *slot = smem + (pr_step % kRing) * kBufFloats;
+                f32x2 top[2][kCKd], bot[2][kCKd];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c = 0; c < kCKd; ++c) {       // channels past C fail the range check and read as 0 (ragged last chunk)
+                        top[k][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, otop[k], c * plane * 4, 0));
+                        bot[k][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, obot[k], c * plane * 4, 0));
+                    }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c = 0; c < kCKd; ++c)
+                        slot[c * kS2Rows * kPitch + ldsoff[k]] =
+                            pwc_warp::blend4(top[k][c][0], top[k][c][1], bot[k][c][0], bot[k][c][1], wgt[k][0], wgt[k][1], wgt[k][2], wgt[k][3]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile is in LDS before this wave reaches the barrier
+                ++pr_step;
+                if (++pr_chunk == nchunks) { pr_chunk = 0; pr_tile += stride; }
+            };
+#pragma unroll
+            for (int k = 0; k < kRing - 1; ++k) produce();
+            for (int s = 0; s < nsteps; ++s) {
+                __builtin_amdgcn_s_barrier();      // B_s: chunk s is readable, slot (s-1)%R is free
+                produce();                         // chunk s+R-1 -> slot (s-1)%R
+            }
+            return;
+        }
     }
 
     // ================= consumers: wave = displacement row dy, lane = 4 pixels x 9 dx ======================
@@ -611,8 +706,8 @@ int launch_corr(const void *in1, const void *in2, void *out, int B, int C, int H
         if constexpr (sizeof(T) == 4) {
             if (vec && (int64_t)H * W * kCKd * 4 < 0x7fffffffLL) {
                 const int grid = (int)((nblk < kPersistentPerCU * 256) ? nblk : kPersistentPerCU * 256);
-                hipLaunchKernelGGL(corr81_dma_kernel, dim3((unsigned)grid), dim3(kThreadsDma), 0, st,
-                                   a, b, o, C, H, W, tiles_x, tiles_y, (int)nblk, bs1, bs2, bso, scale, slope, do_leaky);
+                hipLaunchKernelGGL(corr81_dma_kernel<false>, dim3((unsigned)grid), dim3(kThreadsDma), 0, st,
+                                   a, b, o, C, H, W, tiles_x, tiles_y, (int)nblk, bs1, bs2, bso, scale, slope, do_leaky, WarpArgs{});
                 return pwc::check_launch("corr81_dma_kernel");
             }
         }
@@ -656,6 +751,35 @@ extern "C" int pwc_corr_fwd(const void *in1, const void *in2, void *out,
         default:
             PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr_fwd: dtype %d", dtype);
     }
+}
+
+extern "C" int pwc_warp_corr81_fwd(const void *in1, const void *x2, const void *flo, void *out, int B, int C, int H, int W,
+                                   float flow_scale, int align_corners, float mask_threshold,
+                                   float corr_multiply, unsigned flags, float leaky_slope,
+                                   int64_t in1_bstride, int64_t x2_bstride, int64_t flo_bstride, int64_t out_bstride, void *stream) {
+    if (!in1 || !x2 || !flo || !out) PWC_FAIL(PWC_EINVAL, "pwc_warp_corr81_fwd: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_warp_corr81_fwd: bad shape %dx%dx%dx%d", B, C, H, W);
+    const int64_t plane = (int64_t)H * W;
+    if (in1_bstride < C * plane || x2_bstride < C * plane || flo_bstride < 2 * plane || out_bstride < 81 * plane)
+        PWC_FAIL(PWC_EINVAL, "pwc_warp_corr81_fwd: batch stride smaller than the tensor");
+    const uintptr_t al = reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(out);
+    if ((W % 4) || (al & 15u) || (in1_bstride % 4) || (x2_bstride % 4) || (out_bstride % 4) || (reinterpret_cast<uintptr_t>(flo) & 3u) ||
+        plane * kCKd * 4 >= 0x7fffffffLL) {
+        pwc::set_error("pwc_warp_corr81_fwd: needs W %% 4 == 0, 16-byte aligned operands and H*W*16 < 2^31 (call pwc_warp_fwd + pwc_corr_fwd instead)");
+        return PWC_EUNSUPPORTED;
+    }
+    const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kTH - 1) / kTH;
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_warp_corr81_fwd: grid too large");
+    const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
+    static const int per_cu = [] { const char *e = getenv("PWC_WARPCORR_PER_CU"); return (e && *e) ? atoi(e) : kPersistentPerCU; }();
+    const int grid = (int)((nblk < per_cu * 256) ? nblk : per_cu * 256);
+    const WarpArgs wa{static_cast<const float *>(flo), flo_bstride, flow_scale, mask_threshold, align_corners};
+    hipLaunchKernelGGL(corr81_dma_kernel<true>, dim3((unsigned)grid), dim3(kThreadsWarp), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(in1), static_cast<const float *>(x2), static_cast<float *>(out), C, H, W,
+                       tiles_x, tiles_y, (int)nblk, in1_bstride, x2_bstride, out_bstride, scale, leaky_slope,
+                       (flags & PWC_ACT_LEAKY) ? 1 : 0, wa);
+    return pwc::check_launch("corr81_dma_kernel<warp>");
 }
 
 extern "C" int pwc_corr_bwd(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,

@@ -17,6 +17,7 @@
 // smooth flow field stay within a few cache lines per wave.  HBM-bound: algorithmic bytes
 // (2*C + 2)*H*W*sizeof(T) per image.
 #include "pwc_common.h"
+#include "pwc_warp_taps.h"
 
 namespace {
 
@@ -26,52 +27,9 @@ using pwc::to_f32;
 constexpr int kWarpThreads = 256;
 constexpr int kCPT = 8;  // channels per thread-iteration block (gridDim.y splits C)
 
-struct Taps {
-    int o00, o01, o10, o11;     // element offsets inside a plane (clamped, always valid)
-    float w00, w01, w10, w11;   // bilinear weight * in-bounds * mask
-};
-
-__device__ __forceinline__ Taps make_taps(float px, float py, int H, int W, int align_corners, float thr) {
-    const float gx = 2.0f * px / (float)max(W - 1, 1) - 1.0f;
-    const float gy = 2.0f * py / (float)max(H - 1, 1) - 1.0f;
-    float ix, iy;
-    if (align_corners) {
-        ix = (gx + 1.0f) / 2.0f * (float)(W - 1);
-        iy = (gy + 1.0f) / 2.0f * (float)(H - 1);
-    } else {
-        ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
-        iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
-    }
-    // keep the integer conversion defined for wild flows; anything this far out has no valid tap
-    ix = fminf(fmaxf(ix, -16.0f), (float)W + 16.0f);
-    iy = fminf(fmaxf(iy, -16.0f), (float)H + 16.0f);
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const float ax1 = ix - fx, ay1 = iy - fy;
-    const float ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
-    const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x0 + 1 >= 0) && (x0 + 1 < W);
-    const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y0 + 1 >= 0) && (y0 + 1 < H);
-    Taps t;
-    t.w00 = (vx0 && vy0) ? ay0 * ax0 : 0.0f;
-    t.w01 = (vx1 && vy0) ? ay0 * ax1 : 0.0f;
-    t.w10 = (vx0 && vy1) ? ay1 * ax0 : 0.0f;
-    t.w11 = (vx1 && vy1) ? ay1 * ax1 : 0.0f;
-    // grid_sample(ones) accumulates nw, ne, sw, se in this order (same order as the value sum)
-    const float msum = ((t.w00 + t.w01) + t.w10) + t.w11;
-    if (!(msum >= thr)) { t.w00 = t.w01 = t.w10 = t.w11 = 0.0f; }
-    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
-    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
-    t.o00 = yc0 * W + xc0;
-    t.o01 = yc0 * W + xc1;
-    t.o10 = yc1 * W + xc0;
-    t.o11 = yc1 * W + xc1;
-    return t;
-}
-
-__device__ __forceinline__ float tap4(const Taps &t, float v00, float v01, float v10, float v11) {
-    // same association as grid_sample's CPU kernel: ((nw + ne) + sw) + se
-    return ((v00 * t.w00 + v01 * t.w01) + v10 * t.w10) + v11 * t.w11;
-}
+using pwc_warp::Taps;
+using pwc_warp::make_taps;
+using pwc_warp::tap4;
 
 template <typename T>
 __global__ void __launch_bounds__(kWarpThreads)

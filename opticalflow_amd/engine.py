@@ -19,6 +19,7 @@ captured into a HIP graph (``PWCDCNet.forward(..., )`` does that when ``use_grap
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -84,6 +85,7 @@ class PwcPlan:
         self.align_corners = align_corners
         self.conv_backend = conv_backend
         self.variant = variant
+        self.fuse_warp = os.environ.get("PWC_FUSE_WARP_CORR", "1") != "0"     # 0: warp and correlation as two launches (A/B runs)
         self.pyramid_names = PYRAMID_NAMES if variant == "dc" else PYRAMID_NAMES_OLD
         self.mask_threshold = 0.9999 if variant == "dc" else 0.999        # PWCNet.py:174 / :400
         self.p = dict(params)
@@ -219,10 +221,18 @@ class PwcPlan:
                 # dense block's input, PWCNet.py:215); c2 is only ever read by the warp
                 ar[:, off:off + c].copy_(self.c1[l])
                 up_flow = ar[:, off + c:off + c + 2]
-                ops.warp(self.c2[l], up_flow, flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
-                         mask_threshold=self.mask_threshold, out=self.warped[l])
-                ops.correlation(ar[:, off:off + c], self.warped[l], self.md, 1, self.md, 1, 1, 1.0,
-                                normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+                # warp + correlation + LeakyReLU as one kernel (the warped features live in LDS only) where the geometry
+                # allows it (md = 4, W % 4 == 0); otherwise the two operators
+                fused = None
+                if self.fuse_warp and self.md == 4:
+                    fused = ops.warp_correlation(ar[:, off:off + c], self.c2[l], up_flow, flow_scale=WARP_SCALE[l],
+                                                 align_corners=self.align_corners, mask_threshold=self.mask_threshold,
+                                                 normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+                if fused is None:
+                    ops.warp(self.c2[l], up_flow, flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
+                             mask_threshold=self.mask_threshold, out=self.warped[l])
+                    ops.correlation(ar[:, off:off + c], self.warped[l], self.md, 1, self.md, 1, 1, 1.0,
+                                    normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
             lo = base
             for i, (co, off_i) in enumerate(zip(DENSE_OUT, DENSE_OFF)):
                 self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, off_i:off_i + co])

@@ -117,6 +117,36 @@ def correlation_backward(in1: torch.Tensor, in2: torch.Tensor, grad_out: torch.T
     return g1, g2
 
 
+def warp_correlation(in1: torch.Tensor, x2: torch.Tensor, flo: torch.Tensor, flow_scale: float = 1.0,
+                     align_corners: bool = False, mask_threshold: float = 0.9999, corr_multiply: float = 1.0,
+                     normalize: bool = False, leaky_slope: Optional[float] = None,
+                     out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """correlation(in1, warp(x2, flow_scale * flo)) for PWC-Net's configuration (pad 4, k 1, d 4, strides 1) in ONE kernel:
+    the warped tensor is produced tile by tile in LDS and never written to HBM (PWCNet.py:212-213 etc.).  Bit-identical to
+    warp() followed by correlation().  Returns None (nothing launched) when the geometry is outside the fused kernel
+    (W % 4 != 0 or unaligned operands): call the two operators then."""
+    lib = _lib.load()
+    bs1, bs2, bsf = _plane_dense(in1, "in1"), _plane_dense(x2, "x2"), _plane_dense(flo, "flo")
+    B, C, H, W = in1.shape
+    if in1.dtype != torch.float32 or x2.shape != in1.shape or x2.dtype != in1.dtype or tuple(flo.shape) != (B, 2, H, W) \
+            or flo.dtype != in1.dtype or x2.device != in1.device or flo.device != in1.device:
+        raise ValueError("in1, x2 must be float32 [B,C,H,W] and flo [B,2,H,W] on one device")
+    if out is None:
+        out = torch.empty((B, 81, H, W), dtype=in1.dtype, device=in1.device)
+    elif tuple(out.shape) != (B, 81, H, W) or out.dtype != in1.dtype or out.device != in1.device:
+        raise ValueError("out must be %s" % ((B, 81, H, W),))
+    bso = _plane_dense(out, "out")
+    flags = (FLAG_CORR_NORMALIZE if normalize else 0) | (FLAG_ACT_LEAKY if leaky_slope is not None else 0)
+    with torch.cuda.device(in1.device):
+        rc = lib.pwc_warp_corr81_fwd(in1.data_ptr(), x2.data_ptr(), flo.data_ptr(), out.data_ptr(), B, C, H, W,
+                                     float(flow_scale), 1 if align_corners else 0, float(mask_threshold),
+                                     float(corr_multiply), flags, float(leaky_slope or 0.0), bs1, bs2, bsf, bso, _stream(in1))
+    if rc == -2:                               # PWC_EUNSUPPORTED: geometry outside the fused kernel
+        return None
+    check(rc, "pwc_warp_corr81_fwd")
+    return out
+
+
 def warp(x: torch.Tensor, flo: torch.Tensor, flow_scale: float = 1.0, align_corners: bool = False,
          mask_threshold: float = 0.9999, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()

@@ -91,6 +91,39 @@ def test_corr_properties_full_size(dev):
     assert (c[:, 0, :4, :] == 0).all() and (c[:, 80, -4:, :] == 0).all()
 
 
+@pytest.mark.parametrize("shape,scale,align", [((2, 32, 24, 64), 5.0, False), ((1, 64, 56, 128), 2.5, True), ((3, 13, 20, 44), 1.25, False),
+                                               ((2, 128, 14, 32), 0.625, False), ((16, 32, 112, 256), 5.0, False)])
+def test_warp_correlation_fused_equals_two_kernels(dev, shape, scale, align):
+    """pwc_warp_corr81_fwd (warp producer waves + LDS-DMA loader + nine fma waves in one persistent kernel) is BIT-IDENTICAL to
+    pwc_warp_fwd followed by pwc_corr_fwd -- flows that leave the image, ragged tiles, ragged channel chunks, arena-strided
+    operands, both scale modes -- and agrees with the oracle."""
+    from opticalflow_amd import ops
+    B, C, H, W = shape
+    c1 = seeded_rand(shape, 70, -1, 1).to(dev)
+    c2 = seeded_rand(shape, 71, -1, 1).to(dev)
+    flo = seeded_rand((B, 2, H, W), 72, -3, 3)
+    flo[0, :, : H // 3] *= 4.0                                        # part of image 0 samples far outside
+    flo = flo.to(dev)
+    arena = torch.full((B, 81 + C + 2, H, W), 7.0, device=dev)         # [corr slot | c1 | up_flow] like the plan's arena
+    arena[:, 81:81 + C].copy_(c1)
+    arena[:, 81 + C:].copy_(flo)
+    got = ops.warp_correlation(arena[:, 81:81 + C], c2, arena[:, 81 + C:], flow_scale=scale, align_corners=align,
+                               leaky_slope=0.1, out=arena[:, :81])
+    assert got is not None
+    warped = ops.warp(c2, flo, flow_scale=scale, align_corners=align)
+    two = ops.correlation(c1, warped, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1)
+    assert torch.equal(arena[:, :81], two)
+    assert torch.equal(arena[:, 81:81 + C], c1) and torch.equal(arena[:, 81 + C:], flo)            # neighbours untouched
+    gotn = ops.warp_correlation(c1, c2, flo, flow_scale=scale, align_corners=align, normalize=True)
+    assert torch.equal(gotn, ops.correlation(c1, warped, 4, 1, 4, 1, 1, 1.0, normalize=True))
+    if B * H * W <= 100000:
+        ref = O.leaky_relu(O.correlation(c1.cpu(), O.warp(c2.cpu(), flo.cpu() * scale, align_corners=align), 4, 1, 4, 1, 1, 1))
+        assert (arena[:, :81].cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(ops.warp_correlation(c1, c2, flo, flow_scale=scale, align_corners=align, leaky_slope=0.1), two)   # repeatable
+    # outside the fused kernel's geometry: nothing launched, caller falls back
+    assert ops.warp_correlation(c1[..., :-1].contiguous(), c2[..., :-1].contiguous(), flo[..., :-1].contiguous()) is None
+
+
 def test_corr_backward_matches_autograd_of_oracle(dev):
     from opticalflow_amd import ops
     a = seeded_rand((2, 6, 9, 11), 20, -1, 1).requires_grad_(True)
