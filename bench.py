@@ -150,36 +150,48 @@ def probes_fp32(result, args, plan, B, H, W, h2, w2, stream):
     c2 = 32
     off = 448 + 81
     ar = plan.arena[2]
-    # three operand sets laid out like the arena's (corr slot | c1) channels + a warped tensor each
-    sets = [(torch.empty((B, 81 + c2, h2, w2), device=ar.device), torch.empty((B, c2, h2, w2), device=ar.device)) for _ in range(3)]
-    for mini, wrp in sets:
-        mini[:, 81:].copy_(ar[:, off:off + c2])
+    # three operand sets laid out like the arena's (corr slot | c1 | up_flow) channels + the second image's features each
+    sets = [(torch.empty((B, 81 + c2 + 2, h2, w2), device=ar.device), torch.empty((B, c2, h2, w2), device=ar.device),
+             torch.empty((B, c2, h2, w2), device=ar.device)) for _ in range(3)]
+    for mini, feat2, wrp in sets:
+        mini[:, 81:].copy_(ar[:, off:off + c2 + 2])
+        feat2.copy_(plan.c2[2])
         wrp.copy_(plan.warped[2])
-    bytes_corr = (2 * c2 + 81) * h2 * w2 * 4 * B
-    ms = event_time_ms([(lambda m=m, w_=w_: ops.correlation(m[:, 81:], w_, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1, out=m[:, :81]))
-                        for m, w_ in sets], PROBE_REPS, stream)
-    gbs = bytes_corr / (ms * 1e-3) / 1e9
-    rec = pmc_record("corr81_level2_b16", full)
-    result["roofline_corr"] = {"kernel": "corr81_dma_kernel (level 2: C=32 @%dx%d, B=%d, fused LeakyReLU, arena-strided write; "
-                                         "3 operand sets in rotation)" % (w2, h2, B),
+    # (a) what levels 5..2 of the forward run: warp + correlation + LeakyReLU in one kernel
+    bytes_fused = (2 * c2 + 81 + 2) * h2 * w2 * 4 * B
+    ms = event_time_ms([(lambda m=m, f=f: ops.warp_correlation(m[:, 81:81 + c2], f, m[:, 81 + c2:], flow_scale=5.0, leaky_slope=0.1,
+                                                               out=m[:, :81])) for m, f, _ in sets], PROBE_REPS, stream)
+    gbs = bytes_fused / (ms * 1e-3) / 1e9
+    rec = pmc_record("warp_corr81_level2_b16", full)
+    result["roofline_corr"] = {"kernel": "corr81_dma_kernel<warp> = warp + 81-channel correlation + LeakyReLU fused (level 2: C=32 @%dx%d, B=%d, "
+                                         "arena-strided operands; 3 operand sets in rotation)" % (w2, h2, B),
                                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
                                "traffic": rec.get("traffic"), "traffic_source": rec.get("traffic_source"),
-                               "avg_launch_ms": round(ms, 4), "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_corr}
+                               "avg_launch_ms": round(ms, 4), "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_fused}
     if "rocprof_avg_ms" in rec:
-        result["roofline_corr"]["frac_rocprof"] = round(bytes_corr / (rec["rocprof_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        result["roofline_corr"]["frac_rocprof"] = round(bytes_fused / (rec["rocprof_avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    # (b) the two kernels it replaces (still the C-ABI entries pwc_corr_fwd / pwc_warp_fwd; level 6 runs the plain correlation)
+    bytes_corr = (2 * c2 + 81) * h2 * w2 * 4 * B
+    ms_c = event_time_ms([(lambda m=m, w_=w_: ops.correlation(m[:, 81:81 + c2], w_, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1, out=m[:, :81]))
+                          for m, _, w_ in sets], PROBE_REPS, stream)
+    rec = pmc_record("corr81_level2_b16", full)
+    result["roofline_corr_plain"] = {"kernel": "corr81_dma_kernel (correlation alone, same operands)", "bound": "hbm",
+                                     "achieved": round(bytes_corr / (ms_c * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(bytes_corr / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": rec.get("traffic"),
+                                     "traffic_source": rec.get("traffic_source"), "avg_launch_ms": round(ms_c, 4),
+                                     "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_corr}
     if args.conv_backend != "hip":
         result["roofline"] = result["roofline_corr"]
     bytes_warp = (2 * c2 + 2) * h2 * w2 * 4 * B
-    srcs = [plan.c2[2].clone() for _ in range(3)]
-    flo = ar[:, off + c2:off + c2 + 2]
-    ms = event_time_ms([(lambda s_=s_, w_=w_: ops.warp(s_, flo, 5.0, False, out=w_)) for s_, (_, w_) in zip(srcs, sets)],
-                       PROBE_REPS, stream)
-    result["roofline_warp"] = {"kernel": "warp_kernel<f32> (level 2; 3 operand sets in rotation)", "bound": "hbm",
-                               "achieved": round(bytes_warp / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(bytes_warp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
+    ms_w = event_time_ms([(lambda m=m, f=f, w_=w_: ops.warp(f, m[:, 81 + c2:], 5.0, False, out=w_)) for m, f, w_ in sets],
+                         PROBE_REPS, stream)
+    result["roofline_warp"] = {"kernel": "warp_kernel<f32> (warp alone, level 2; 3 operand sets in rotation)", "bound": "hbm",
+                               "achieved": round(bytes_warp / (ms_w * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(bytes_warp / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms_w, 4),
                                "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_warp}
-    del sets, srcs
+    result["roofline_corr"]["replaces_ms"] = round(ms_c + ms_w, 4)
+    del sets
 
 
 def probes_fp16(result, plan, B, H, W, h2, w2, stream):

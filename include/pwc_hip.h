@@ -227,6 +227,11 @@ int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const void *head_bia
                         int B, int Cin, int H, int W, int dtype,
                         int64_t x_bstride, int64_t flow_bstride, int64_t up_bstride, void *stream);
 
+/* Profiling calibration, not on the product path: streams `nbytes` (a multiple of 64*width) of src through LDS with the
+ * kernels' own LDS-DMA instruction (width 4: buffer_load_dword ... lds, width 16: buffer_load_dwordx4 ... lds) so that rocprofv3's
+ * FETCH_SIZE can be calibrated on a known byte count in this access pattern (MI355X guide, HBM section).  sums: blocks*256 floats. */
+int pwc_calib_lds_dma_read(const void *src, void *sums, int64_t nbytes, int width, int blocks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

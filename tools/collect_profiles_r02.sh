@@ -1,0 +1,60 @@
+#!/bin/bash
+# Round-2 evidence, collected on the GPU box into gpurun_out/final_r02/ (tools/install_profiles_r02.py copies it into profiles/).
+# rocprofv3 runs from /tmp (TMPDIR=/tmp) with the program itself after `--`; PMC passes are separate runs.
+set -u
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/gpurun_out/final_r02"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+say() { echo "[collect $(date +%H:%M:%S)] $*"; }
+
+say "bench lines: fp32 default, fp16, kitti stream"
+python3 "$ROOT/bench.py" > "$OUT/bench_b16.json" 2> "$OUT/bench_b16.stderr.log"
+python3 "$ROOT/bench.py" --precision fp16 --no-cpu-baseline > "$OUT/f16_bench_b16.json" 2> "$OUT/f16_bench_b16.stderr.log"
+python3 "$ROOT/bench.py" --workload kitti > "$OUT/kitti_bench.json" 2> /dev/null
+python3 "$ROOT/bench.py" --workload kitti --precision fp32 > "$OUT/kitti_bench_fp32.json" 2> /dev/null
+for b in 1 4 32; do
+  python3 "$ROOT/bench.py" --batch $b --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/bench_b$b.json" 2> /dev/null
+  python3 "$ROOT/bench.py" --precision fp16 --batch $b --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/f16_bench_b$b.json" 2> /dev/null
+done
+
+say "kernel traces + timelines"
+bash "$ROOT/tools/collect_timelines.sh" > /dev/null 2>&1
+cp "$ROOT/gpurun_out/tl/timeline_fp32.txt" "$OUT/forward_timeline_b16.txt"
+cp "$ROOT/gpurun_out/tl/timeline_fp16.txt" "$OUT/f16_forward_timeline_b16.txt"
+cp "$ROOT/gpurun_out/tl/kernel_stats_fp32.csv" "$OUT/kernel_stats_bench_b16.csv"
+cp "$ROOT/gpurun_out/tl/kernel_stats_fp16.csv" "$OUT/f16_kernel_stats_bench_b16.csv"
+
+say "dominant kernels alone (rocprofv3 averages): dc_conv1 fp32 / fp16, fused warp+corr, backward kernels"
+rocprofv3 --kernel-trace --stats -d "$OUT/p1" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv.py" dc_conv1 > "$OUT/microbench_dc_conv1.txt" 2>&1
+cp "$(find "$OUT/p1" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_dc_conv1.csv"; rm -rf "$OUT/p1"
+rocprofv3 --kernel-trace --stats -d "$OUT/p2" -o p --output-format csv -- python3 "$ROOT/tools/bench_warpcorr.py" > "$OUT/microbench_warpcorr.txt" 2>&1
+cp "$(find "$OUT/p2" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_warpcorr.csv"; rm -rf "$OUT/p2"
+rocprofv3 --kernel-trace --stats -d "$OUT/p3" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
+cp "$(find "$OUT/p3" -name "*kernel_stats.csv" | head -1)" "$OUT/f16_kernel_stats_dc_conv1.csv"; rm -rf "$OUT/p3"
+python3 "$ROOT/tools/bench_conv_f16.py" > "$OUT/f16_microbench_conv.txt" 2>&1
+python3 "$ROOT/tools/bench_bwd.py" > "$OUT/microbench_bwd.txt" 2>&1
+python3 "$ROOT/tools/bench_pyr1.py" > "$OUT/microbench_pyr1.txt" 2>&1
+python3 "$ROOT/tools/bench_corr.py" > "$OUT/microbench_corr.txt" 2>&1
+
+say "PMC passes (one counter per run): calibration, dc_conv1 fp32 / fp16, fused warp+corr, plain corr"
+: > "$OUT/pmc_summary.txt"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/calib_fetch.py" > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "calib_dma_read_kernelILi4E" $c >> "$OUT/pmc_summary.txt"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "calib_dma_read_kernelILi16E" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv.py" dc_conv1 > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_mfma_kernel $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+  PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_warpcorr.py" > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernelILb1E" $c >> "$OUT/pmc_summary.txt"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernelILb0E" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+done
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+done
+say "done"
+cat "$OUT/pmc_summary.txt"
+ls "$OUT"
