@@ -41,15 +41,15 @@ say "PMC passes (one counter per run): calibration, dc_conv1 fp32 / fp16, fused 
 : > "$OUT/pmc_summary.txt"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/calib_fetch.py" > /dev/null 2>&1
-  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "calib_dma_read_kernelILi4E" $c >> "$OUT/pmc_summary.txt"
-  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "calib_dma_read_kernelILi16E" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "calib_dma_read_kernel<4>" $c >> "$OUT/pmc_summary.txt"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "calib_dma_read_kernel<16>" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv.py" dc_conv1 > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_mfma_kernel $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_warpcorr.py" > /dev/null 2>&1
-  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernelILb1E" $c >> "$OUT/pmc_summary.txt"
-  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernelILb0E" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernel<true>" $c >> "$OUT/pmc_summary.txt"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernel<false>" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
 done
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1

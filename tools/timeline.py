@@ -27,7 +27,9 @@ def short(n):
     m = re.search(r"stream3x3_kernel<(\d+), (\d+), (\d+)>", n)
     if m:
         return "stream3x3<mode%s,TH%s,KS%s>" % m.groups()
-    for k in ("corr81_c8", "warp_c8", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
+    if "corr81_dma_kernel<true>" in n or "corr81_dma_kernelILb1E" in n:
+        return "warp+corr81"
+    for k in ("pyr1_fused", "corr81_bwd", "corr81_c8", "warp_c8", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
         if k in n:
             return k
     for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "splitk_reduce", "warp_kernel", "copyBuffer", "elementwise", "pack3x3"):
@@ -44,8 +46,9 @@ def main():
             min_grid = int(a.split("=")[1])
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [short(r["Kernel_Name"]) for r in rows]
-    if "--fp32" not in sys.argv and any(n == "image_conv_s2" for n in names):   # fp16 plan: a forward starts with conv1a on the two images
-        starts = [i for i in range(len(rows) - 1) if names[i] == "image_conv_s2" and names[i + 1] == "image_conv_s2"
+    first16 = "pyr1_fused" if any(n == "pyr1_fused" for n in names) else "image_conv_s2"
+    if "--fp32" not in sys.argv and any(n == first16 for n in names):   # fp16 plan: a forward starts with the first layer on the two images
+        starts = [i for i in range(len(rows) - 1) if names[i] == first16 and names[i + 1] == first16
                   and int(rows[i]["Grid_Size_X"]) > min_grid]
         rows_ok = True
     else:
@@ -61,7 +64,7 @@ def main():
         def span(i):
             return int(rows[starts[i + 1]]["Start_Timestamp"]) - int(rows[starts[i]]["Start_Timestamp"])
         pure = [i for i in range(len(starts) - 1)
-                if not any(n.startswith("f16conv") or n == "image_conv_s2" for n in names[starts[i]:starts[i + 1]])]
+                if not any(n.startswith("f16conv") or n.startswith("f16w8") or n in ("image_conv_s2", "pyr1_fused") for n in names[starts[i]:starts[i + 1]])]
         best = min(span(i) for i in pure)
         i = [i for i in pure if span(i) <= 1.2 * best][-1]
         s, e = starts[i], starts[i + 1]
