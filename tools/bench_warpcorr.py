@@ -28,7 +28,10 @@ def t(fns, reps=30):
     return s.elapsed_time(e) / reps * 1e3
 
 
+LEVELS = [int(v) for v in os.environ.get("PWC_BENCH_LEVELS", "2,3,4,5").split(",")]       # profiler passes look at level 2 only
 for lvl, C, H, W, scale in ((2, 32, 112, 256, 5.0), (3, 64, 56, 128, 2.5), (4, 96, 28, 64, 1.25), (5, 128, 14, 32, 0.625)):
+    if lvl not in LEVELS:
+        continue
     sets = []
     for _ in range(3):
         c1 = torch.randn(B, C, H, W, generator=g).to(dev)
