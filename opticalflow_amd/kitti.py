@@ -207,6 +207,15 @@ def load_flow_kitti_png(path: str) -> Tuple[np.ndarray, np.ndarray]:
 
 
 # ------------------------------------------------------------------ double-buffered ingest (BASELINE config 5)
+def _host_u8(img) -> torch.Tensor:
+    """A host image as a uint8 tensor view: cv2.imread hands the reference's loop numpy arrays (inference_kitti.py:236-237),
+    the synthetic streams hand tensors; both are accepted, anything that is not uint8 [H,W,>=3] is refused."""
+    t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+    if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] < 3:
+        raise ValueError("an image must be uint8 [H,W,>=3], got %s %s" % (t.dtype, tuple(t.shape)))
+    return t
+
+
 class PairStream:
     """Iterate device-resident normalised pairs from host uint8 pairs with upload/compute overlap.
     ``raw=True`` yields the uploaded uint8 tensor [2,H,W,3] instead (for GraphedInfer, which normalises inside
@@ -221,16 +230,16 @@ class PairStream:
         self.uploaded = [None, None]       # event of the last upload that read each staging buffer
 
     def _stage(self, slot: int, pair):
-        a, b = pair
+        a, b = _host_u8(pair[0]), _host_u8(pair[1])
         shape = (2,) + tuple(a.shape[:2]) + (3,)                               # [2,H,W,3] uint8
-        if tuple(b.shape[:2]) != tuple(a.shape[:2]) or a.dtype != torch.uint8 or b.dtype != torch.uint8:
+        if tuple(b.shape[:2]) != tuple(a.shape[:2]):
             raise ValueError("a pair must be two uint8 [H,W,>=3] images of the same size")
         if self.slots[slot] is None or tuple(self.slots[slot].shape) != shape:
             self.slots[slot] = torch.empty(shape, dtype=torch.uint8).pin_memory()
         elif self.uploaded[slot] is not None:
             self.uploaded[slot].synchronize()      # the DMA that last read this buffer must be done before it is rewritten
-        self.slots[slot][0].copy_(a[..., :3])      # straight into pinned memory (an intermediate torch.stack cost 5 ms/pair)
-        self.slots[slot][1].copy_(b[..., :3])
+        self.slots[slot][0].copy_(_host_u8(a)[..., :3])      # straight into pinned memory (an intermediate torch.stack cost 5 ms/pair)
+        self.slots[slot][1].copy_(_host_u8(b)[..., :3])
         with torch.cuda.stream(self.copy_stream):
             dev = self.slots[slot].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
@@ -317,8 +326,8 @@ class BatchStream:
                 self.uploaded[slot].synchronize()
             if tuple(a.shape[:2]) != tuple(self.slots[slot].shape[2:4]) or tuple(b.shape[:2]) != tuple(a.shape[:2]):
                 raise ValueError("BatchStream needs pairs of one size")
-            self.slots[slot][n, 0].copy_(a[..., :3])
-            self.slots[slot][n, 1].copy_(b[..., :3])
+            self.slots[slot][n, 0].copy_(_host_u8(a)[..., :3])
+            self.slots[slot][n, 1].copy_(_host_u8(b)[..., :3])
             n += 1
             if n == self.batch:
                 break

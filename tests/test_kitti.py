@@ -217,3 +217,15 @@ def test_kitti_fp16_full_size_stream(gpu_device):
     got4 = torch.cat(outs, 0)
     ref1 = torch.cat(got, 0)
     assert O.epe(got4.cpu(), ref1.cpu()) < 1.8e-3 * ref1.abs().mean().item()
+
+
+def test_host_images_numpy_or_tensor():
+    """The ingest accepts what cv2.imread returns (numpy uint8 HxWx3/4) as well as tensors and refuses anything else."""
+    a = np.arange(2 * 3 * 4, dtype=np.uint8).reshape(2, 3, 4)
+    t = kitti._host_u8(a)
+    assert isinstance(t, torch.Tensor) and t.dtype == torch.uint8 and tuple(t.shape) == (2, 3, 4)
+    assert torch.equal(t, torch.from_numpy(a)) and kitti._host_u8(t) is t
+    assert torch.equal(kitti._host_u8(a[:, ::-1]), torch.from_numpy(a[:, ::-1].copy()))          # negative strides (cv2 flips)
+    for bad in (a.astype(np.float32), a[..., :2], a[0]):
+        with pytest.raises(ValueError):
+            kitti._host_u8(bad)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput with S independent forwards in flight on S HIP streams (one captured plan each, batch B per forward) against the
 single-stream back-to-back replay bench.py measures.  The coarse decoder levels and the small pyramid levels launch 16-128
-workgroups on 256 CUs; a second forward's large kernels can fill those holes.  usage: bench_streams.py [fp32|fp16] [B] [steps]"""
+workgroups on 256 CUs; a second forward's large kernels can fill those holes.  usage: [PWC_BENCH_STREAMS=1,2,4] bench_streams.py [fp32|fp16] [B] [steps]"""
 import os
 import sys
 import time
@@ -18,7 +18,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 dev = torch.device("cuda:0")
 H, W = 448, 1024
 sd = None
-for S in (1, 2, 3):
+for S in [int(v) for v in os.environ.get("PWC_BENCH_STREAMS", "1,2,3").split(",")]:
     nets, xs, streams = [], [], []
     for s in range(S):
         net = PWCDCNet(use_graph=True, precision=prec).to(dev).eval()
