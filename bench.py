@@ -323,7 +323,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)       # >= 100 timed, >= 20 warm-up forwards
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default 16; 4 for --workload kitti)")
+    ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default 16)")
     ap.add_argument("--workload", default="pairs", choices=["pairs", "kitti"],
                     help="pairs = the headline metric (resident 1024x448 batch, BASELINE configs[2]/[3]); kitti = configs[4]: "
                          "375x1242 uint8 pairs streamed from host memory through kitti.ShardedStream (H2D included)")
@@ -339,7 +339,7 @@ def main():
     if args.precision is None:
         args.precision = "fp16" if args.workload == "kitti" else "fp32"
     if args.batch is None:
-        args.batch = 4 if args.workload == "kitti" else 16
+        args.batch = 16
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -216,49 +216,77 @@ def _host_u8(img) -> torch.Tensor:
     return t
 
 
-class PairStream:
-    """Iterate device-resident normalised pairs from host uint8 pairs with upload/compute overlap.
-    ``raw=True`` yields the uploaded uint8 tensor [2,H,W,3] instead (for GraphedInfer, which normalises inside
-    its HIP graph)."""
+class _Ingest:
+    """Host uint8 pairs -> device batches [n,2,H,W,3], one batch ahead of the consumer.
 
-    def __init__(self, pairs: Iterable[Tuple[torch.Tensor, torch.Tensor]], device: torch.device, raw: bool = False):
-        self.pairs = iter(pairs)
-        self.device = device
-        self.raw = raw
+    Batch k+1 is copied into one of two pinned staging buffers and its upload started on a copy stream before batch k is
+    handed out; the consumer's stream waits on the upload's event, and since the consumer only enqueues work (a captured
+    pipeline costs 0.05 ms of host time per replay) the host runs ahead and the copies overlap the previous batch's
+    kernels.  (A producer thread + queue was measured slower than this single-threaded order, 2.5 vs 1.77 ms per step.)
+    A staging buffer is rewritten only after the upload that last read it has completed.  The fill is a plain memcpy per
+    image (numpy.copyto: 11 MB in 0.26 ms on the GPU box); Tensor.copy_ fans a 1.4 MB image out over every OpenMP thread
+    torch sees (128 on a box whose share is 16) and took 2-3 ms for the same bytes, which capped the whole stream at
+    ~1000 pairs/s while the captured pipeline does 2300-3400
+    (tools/host_pin_test.py, tools/bench_kitti_parts.py)."""
+
+    def __init__(self, pairs, device: torch.device, batch: int):
+        self.pairs, self.device, self.batch = iter(pairs), device, batch
         self.copy_stream = torch.cuda.Stream(device=device)
         self.slots = [None, None]          # pinned host staging, allocated on first use per shape
+        self.views = [None, None]          # the same memory as numpy arrays [2*batch, H, W, 3]
         self.uploaded = [None, None]       # event of the last upload that read each staging buffer
 
-    def _stage(self, slot: int, pair):
-        a, b = _host_u8(pair[0]), _host_u8(pair[1])
-        shape = (2,) + tuple(a.shape[:2]) + (3,)                               # [2,H,W,3] uint8
-        if tuple(b.shape[:2]) != tuple(a.shape[:2]):
-            raise ValueError("a pair must be two uint8 [H,W,>=3] images of the same size")
+    def _fill(self, slot: int):
+        imgs = []
+        for a, b in self.pairs:
+            a, b = _host_u8(a), _host_u8(b)
+            if tuple(b.shape[:2]) != tuple(a.shape[:2]) or (imgs and tuple(a.shape[:2]) != tuple(imgs[0].shape[:2])):
+                raise ValueError("a batch needs uint8 [H,W,>=3] images of one size")
+            imgs += [a, b]
+            if len(imgs) == 2 * self.batch:
+                break
+        if not imgs:
+            return None
+        n, (h, w) = len(imgs) // 2, imgs[0].shape[:2]
+        shape = (self.batch, 2, h, w, 3)
         if self.slots[slot] is None or tuple(self.slots[slot].shape) != shape:
             self.slots[slot] = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            self.views[slot] = self.slots[slot].view(2 * self.batch, h, w, 3).numpy()
         elif self.uploaded[slot] is not None:
             self.uploaded[slot].synchronize()      # the DMA that last read this buffer must be done before it is rewritten
-        self.slots[slot][0].copy_(_host_u8(a)[..., :3])      # straight into pinned memory (an intermediate torch.stack cost 5 ms/pair)
-        self.slots[slot][1].copy_(_host_u8(b)[..., :3])
+        for i, img in enumerate(imgs):             # straight into pinned memory (an intermediate torch.stack cost 5 ms/pair)
+            np.copyto(self.views[slot][i], img.numpy()[..., :3])
         with torch.cuda.stream(self.copy_stream):
-            dev = self.slots[slot].to(self.device, non_blocking=True)
+            dev = self.slots[slot][:n].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self.uploaded[slot] = ev
         return dev, ev
 
-    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
-        nxt = next(self.pairs, None)
-        pending = self._stage(0, nxt) if nxt is not None else None
-        slot = 1
+    def batches(self) -> Iterator[torch.Tensor]:
+        pending, slot = self._fill(0), 1
         while pending is not None:
             dev, ev = pending
-            nxt = next(self.pairs, None)
-            pending = self._stage(slot, nxt) if nxt is not None else None   # upload k+1 while k is consumed
+            pending = self._fill(slot)             # batch k+1 is staged and its upload started before batch k is consumed
             slot ^= 1
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            dev.record_stream(torch.cuda.current_stream(self.device))
-            yield dev if self.raw else normalize_pair(dev[0], dev[1])
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            dev.record_stream(cur)
+            yield dev
+
+
+class PairStream(_Ingest):
+    """Iterate device-resident normalised pairs from host uint8 pairs with upload/compute overlap (_Ingest, one pair per
+    step).  ``raw=True`` yields the uploaded uint8 tensor [2,H,W,3] instead (for GraphedInfer, which normalises inside
+    its HIP graph)."""
+
+    def __init__(self, pairs: Iterable[Tuple[torch.Tensor, torch.Tensor]], device: torch.device, raw: bool = False):
+        super().__init__(pairs, device, 1)
+        self.raw = raw
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        for dev in self.batches():
+            yield dev[0] if self.raw else normalize_pair(dev[0, 0], dev[0, 1])
 
 
 class GraphedInfer:
@@ -308,47 +336,12 @@ class GraphedInfer:
         return self.out[:n]
 
 
-class BatchStream:
+class BatchStream(_Ingest):
     """PairStream for batches: yields uint8 device tensors [n,2,H,W,3] (n = batch, fewer for the tail) from host uint8
     pairs of one size, staged in two pinned buffers and uploaded on a side stream while the previous batch computes."""
 
-    def __init__(self, pairs: Iterable[Tuple[torch.Tensor, torch.Tensor]], device: torch.device, batch: int):
-        self.pairs, self.device, self.batch = iter(pairs), device, batch
-        self.copy_stream = torch.cuda.Stream(device=device)
-        self.slots, self.uploaded = [None, None], [None, None]
-
-    def _stage(self, slot: int):
-        n = 0
-        for a, b in self.pairs:
-            if self.slots[slot] is None:
-                self.slots[slot] = torch.empty((self.batch, 2) + tuple(a.shape[:2]) + (3,), dtype=torch.uint8).pin_memory()
-            elif n == 0 and self.uploaded[slot] is not None:
-                self.uploaded[slot].synchronize()
-            if tuple(a.shape[:2]) != tuple(self.slots[slot].shape[2:4]) or tuple(b.shape[:2]) != tuple(a.shape[:2]):
-                raise ValueError("BatchStream needs pairs of one size")
-            self.slots[slot][n, 0].copy_(_host_u8(a)[..., :3])
-            self.slots[slot][n, 1].copy_(_host_u8(b)[..., :3])
-            n += 1
-            if n == self.batch:
-                break
-        if n == 0:
-            return None
-        with torch.cuda.stream(self.copy_stream):
-            dev = self.slots[slot][:n].to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy_stream)
-        self.uploaded[slot] = ev
-        return dev, ev
-
     def __iter__(self) -> Iterator[torch.Tensor]:
-        pending, slot = self._stage(0), 1
-        while pending is not None:
-            dev, ev = pending
-            pending = self._stage(slot)
-            slot ^= 1
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            dev.record_stream(torch.cuda.current_stream(self.device))
-            yield dev
+        return self.batches()
 
 
 def evaluate_pairs(model, samples: Iterable[Tuple[torch.Tensor, torch.Tensor, np.ndarray, np.ndarray]],

@@ -12,6 +12,7 @@ say "bench lines: fp32 default, fp16, kitti stream"
 python3 "$ROOT/bench.py" > "$OUT/bench_b16.json" 2> "$OUT/bench_b16.stderr.log"
 python3 "$ROOT/bench.py" --precision fp16 --no-cpu-baseline > "$OUT/f16_bench_b16.json" 2> "$OUT/f16_bench_b16.stderr.log"
 python3 "$ROOT/bench.py" --workload kitti > "$OUT/kitti_bench.json" 2> /dev/null
+python3 "$ROOT/bench.py" --workload kitti --batch 4 > "$OUT/kitti_bench_b4.json" 2> /dev/null
 python3 "$ROOT/bench.py" --workload kitti --precision fp32 > "$OUT/kitti_bench_fp32.json" 2> /dev/null
 for b in 1 4 32; do
   python3 "$ROOT/bench.py" --batch $b --steps 30 --warmup 5 --no-cpu-baseline > "$OUT/bench_b$b.json" 2> /dev/null

@@ -16,7 +16,7 @@ DST = os.path.join(ROOT, "profiles")
 COPIES = {
     "bench_b16.json": "r02_bench_b16.json", "bench_b16.stderr.log": "r02_bench_b16.stderr.log",
     "f16_bench_b16.json": "r02_f16_bench_b16.json", "f16_bench_b16.stderr.log": "r02_f16_bench_b16.stderr.log",
-    "kitti_bench.json": "r02_kitti_stream_fp16.json", "kitti_bench_fp32.json": "r02_kitti_stream_fp32.json",
+    "kitti_bench.json": "r02_kitti_stream_fp16.json", "kitti_bench_b4.json": "r02_kitti_stream_fp16_b4.json", "kitti_bench_fp32.json": "r02_kitti_stream_fp32.json",
     "forward_timeline_b16.txt": "r02_forward_timeline_b16.txt", "f16_forward_timeline_b16.txt": "r02_f16_forward_timeline_b16.txt",
     "kernel_stats_bench_b16.csv": "r02_kernel_stats_bench_b16.csv", "f16_kernel_stats_bench_b16.csv": "r02_f16_kernel_stats_bench_b16.csv",
     "kernel_stats_dc_conv1.csv": "r02_kernel_stats_dc_conv1_alone.csv", "f16_kernel_stats_dc_conv1.csv": "r02_f16_kernel_stats_dc_conv1_alone.csv",
@@ -99,11 +99,11 @@ def main():
                 continue
             o.write("| %s | %.1f | %.3f | %.3f | %.1f | %.0f |\n" % (tag, d["value"], d["ms_per_step"], d["mfma_util_whole_forward"],
                                                                  d["roofline"]["achieved"], d["roofline_corr"]["achieved"]))
-        for tag, fn in (("KITTI 375x1242 stream fp16, 4 pairs per replay, H2D included", "kitti_bench.json"),
-                        ("KITTI 375x1242 stream fp32, 4 pairs per replay, H2D included", "kitti_bench_fp32.json")):
+        for tag, fn in (("KITTI 375x1242 stream fp16, H2D included", "kitti_bench.json"), ("KITTI stream fp16", "kitti_bench_b4.json"),
+                        ("KITTI 375x1242 stream fp32, H2D included", "kitti_bench_fp32.json")):
             try:
                 d = json.load(open(os.path.join(SRC, fn)))
-                o.write("| %s | %.1f | %.3f | - | - | - |\n" % (tag, d["value"], d["ms_per_step"]))
+                o.write("| %s, %d pairs per replay | %.1f | %.3f | - | - | - |\n" % (tag, d["config"]["pairs_per_gpu"], d["value"], d["ms_per_step"]))
             except (OSError, ValueError):
                 pass
     print(open(os.path.join(DST, "r02_batch_sweep.md")).read())
