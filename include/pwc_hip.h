@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 5
+#define PWC_ABI_VERSION 6
 
 /* element types */
 #define PWC_F32 0
@@ -143,6 +143,17 @@ int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, const void *
                    void *stream);
 /* Bytes of workspace the split-K route of this layer needs (0: the layer never splits; <0: bad shape). */
 int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation);
+
+/* ---- Winograd F(2x2,3x3) route of the same operator (nn.Conv2d 3x3, stride 1, padding 1, dilation 1 + LeakyReLU,
+ * PWCNet.py:26-33), fp32 in / fp32 MFMA accumulation / fp32 out: 16 multiplications per 2x2 outputs instead of 36.
+ * The result differs from pwc_conv2d_fwd only by fp32 rounding (the transforms add and halve; tests bound it).
+ * up = pwc_conv3x3_wino_pack(w) holds G g Gt per (cout, cin) in the kernel's LDS order [chunk of 4 cin][16][2][CoutP][2].
+ * x:[B,Cin,H,W], y:[B,Cout,H,W] with free batch strides (elements); flags: PWC_ACT_LEAKY only. */
+int64_t pwc_conv3x3_wino_packed_bytes(int Cin, int Cout);
+int pwc_conv3x3_wino_pack(const void *w, void *up, int Cin, int Cout, void *stream);
+int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *y,
+                         int B, int Cin, int H, int W, int Cout, unsigned flags, float leaky_slope,
+                         int64_t x_bstride, int64_t y_bstride, void *stream);
 
 /* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------
  * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch

@@ -1,0 +1,387 @@
+// 3x3 / stride 1 / dilation 1 convolution by Winograd F(2x2,3x3) on the gfx950 matrix cores, fp32 throughout.
+// Replaces nn.Conv2d(3x3, padding 1) + LeakyReLU(0.1) (reference models/PWCNet.py:26-33) for the large dense-block and
+// context layers: 16 multiplications per 2x2 outputs instead of 36, i.e. 2.25x fewer MFMA passes than the direct implicit
+// GEMM of pwc_conv_mfma.h for the same fp32 result (up to rounding: the transforms only add and halve).
+//
+//     Y(2x2) = At [ sum_cin (G g Gt) (.) (Bt d B) ] A        d = 4x4 input patch, g = 3x3 filter
+//
+// One GEMM per transform position p = 0..15:  M_p[cout, tile] = sum_cin U_p[cout, cin] * V_p[cin, tile].
+//   U = G g Gt is computed once per model (pwc_conv3x3_wino_pack) and laid out the way the kernel's LDS wants it;
+//   V = Bt d B is computed in the kernel from the raw input tile (LDS -> registers -> LDS), hidden under the MFMAs;
+//   v_mfma_f32_32x32x2_f32: A = U_p (32 couts x 2 cin), B = V_p (2 cin x 32 tiles), D = 32 couts x 32 tiles.
+// A wave owns ONE 32-cout block x ONE group of 32 tiles (4 rows x 32 columns of output) and ALL 16 positions
+// (16 x 16 = 256 accumulator registers), so the output transform At M A happens in the wave's own registers: no exchange.
+// Workgroup = 4 waves = MT cout blocks x (4/MT) tile groups; Cin is consumed in chunks of 4 channels (two MFMA k-steps):
+//     iteration k:  barrier | 32 MFMAs on U(k), V(k), with -- one micro-step in the shadow of each MFMA -- the LDS-DMA of
+//                   raw(k+3) and U(k+2) and the transform raw(k+1) -> V(k+1)
+// LDS: raw [3][4][rows+2][34], U [3][16][2][32*MT][2], V [2][tile groups][16][2][32][2]  (98-124 KiB, one workgroup per CU).
+// Zero padding, ragged edges and the ragged last channel chunk come from the buffer range check (0 into LDS).
+#include <type_traits>
+
+#include "pwc_common.h"
+
+namespace {
+
+using pwc::leaky;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;
+constexpr int kCK = 4;               // input channels per chunk
+constexpr int kTW = 32;              // output columns of a tile group (16 tiles)
+constexpr int kGH = 4;               // output rows of a tile group (2 tile rows)
+constexpr int kRawW = kTW + 2;
+constexpr unsigned kOOB = 0x80000000u;
+
+template <int MT>
+struct Geo {
+    static constexpr int kTG = 4 / MT;                               // tile groups per workgroup
+    static constexpr int kRows = kGH * kTG + 2;
+    static constexpr int kRawPlane = kRows * kRawW;                  // floats per staged channel
+    static constexpr int kRawElems = kCK * kRawPlane;
+    static constexpr int kRawSlots = (kRawElems + kThreads - 1) / kThreads;
+    static constexpr int kRawRegion = kRawSlots * kThreads;
+    static constexpr int kCoutT = 32 * MT;
+    static constexpr int kUFloats = 16 * 2 * kCoutT * 2;             // [pos][kh][cout][step]
+    static constexpr int kUSlots = kUFloats / 4 / kThreads;          // 16-byte pieces per thread: 2*MT
+    static constexpr int kVGroup = 16 * 2 * 32 * 2;                  // [pos][kh][tile][step]
+    static constexpr int kVFloats = kTG * kVGroup;
+    static constexpr int kSmemBytes = (3 * (kRawRegion + kUFloats) + 2 * kVFloats) * 4;         // raw, U: rings of 3; V: 2
+};
+
+// U[chunk][pos][kh][co][step] <- G g Gt of w[co][cin = chunk*4 + 2*step + kh], zero padded
+__global__ void __launch_bounds__(256)
+wino_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, int Cout, int CoutP, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int step = (int)(i & 1);
+    int64_t t = i >> 1;
+    const int co = (int)(t % CoutP);
+    t /= CoutP;
+    const int kh = (int)(t & 1);
+    t >>= 1;
+    const int pos = (int)(t & 15);
+    const int chunk = (int)(t >> 4);
+    const int cin = chunk * kCK + 2 * step + kh;
+    float v = 0.f;
+    if (co < Cout && cin < Cin) {
+        const float *g = w + ((int64_t)co * Cin + cin) * 9;
+        const int pi = pos >> 2, pj = pos & 3;
+        // rows of G: (1,0,0) (1/2,1/2,1/2) (1/2,-1/2,1/2) (0,0,1)
+        const float gi[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float r = 0.f;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) r += g[a * 3 + b] * gi[pj][b];
+            s += gi[pi][a] * r;
+        }
+        v = s;
+    }
+    up[i] = v;
+}
+
+template <int MT>
+__global__ void __launch_bounds__(kThreads, 1)
+conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+                    float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                    int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2) {
+    using G = Geo<MT>;
+    constexpr int TG = G::kTG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *raw = smem;                                  // [3][kRawRegion]
+    float *ubuf = smem + 3 * G::kRawRegion;             // [3][kUFloats]
+    float *vbuf = ubuf + 3 * G::kUFloats;               // [2][kVFloats]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int col = lane & 31;
+    const int kh = lane >> 5;
+
+    int bid = blockIdx.x;
+    // workgroups i, i+8, ... share an XCD: give each XCD a contiguous run of tiles so that halo re-reads hit its L2
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int g = blockIdx.y;
+    const int ox0 = tx * kTW;
+    const int oy0 = ty * (kGH * TG);
+    const int plane = H * W;
+
+    // ---- per-lane DMA source offsets, computed once --------------------------------------------------
+    unsigned raw_off[G::kRawSlots];
+#pragma unroll
+    for (int j = 0; j < G::kRawSlots; ++j) {
+        const int i = j * kThreads + tid;
+        const int c = i / G::kRawPlane;
+        const int rem = i % G::kRawPlane;
+        const int iy = oy0 - 1 + rem / kRawW;
+        const int ix = ox0 - 1 + rem % kRawW;
+        const bool ok = (i < G::kRawElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+        raw_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+    }
+    unsigned u_off[G::kUSlots];
+#pragma unroll
+    for (int j = 0; j < G::kUSlots; ++j) {
+        const int p = j * kThreads + tid;                   // 16-byte piece of the [pos*2+kh][cout][step] image
+        const int row = p / (16 * MT);
+        const int q = p % (16 * MT);
+        u_off[j] = (unsigned)(row * CoutP * 2 + q * 4) * 4u;
+    }
+
+    const float *xb = x + (int64_t)b * bsx;
+    const int nchunks = (Cin + kCK - 1) / kCK;
+    const int64_t uchunk = (int64_t)64 * CoutP;              // floats per chunk of the packed image
+    const float *ug = up + g * G::kCoutT * 2;
+    const int ubytes = (int)(uchunk - g * G::kCoutT * 2) * 4;
+    const unsigned lds_raw = pwc::lds_addr(raw) + wave * 256;         // + slot*kRawRegion*4 + j*1024
+    const unsigned lds_u = pwc::lds_addr(ubuf) + wave * 1024;         // + slot*kUFloats*4 + j*4096
+
+    // ---- one chunk = 32 MFMA slots; the rest of the iteration's work is dealt out one micro-step per slot so that it
+    // issues in the 64-cycle shadow of the preceding MFMA: the LDS-DMA of raw(k+3) and U(k+2), the operand reads of the
+    // next group of four positions, and the transform Bt d B of raw(k+1) (loads / adds / writes of one unit per slot).
+    constexpr int RS = G::kRawSlots, US = G::kUSlots;
+    pwc::v4i32 rs_raw, rs_u;
+    unsigned base_raw = 0, base_u = 0;
+    auto setup_raw = [&](int chunk, int slot) {
+        const int c0 = chunk * kCK;
+        rs_raw = pwc::make_rsrc(xb + (int64_t)c0 * plane, min(kCK, Cin - c0) * plane * 4);
+        base_raw = __builtin_amdgcn_readfirstlane(lds_raw + slot * G::kRawRegion * 4);
+    };
+    auto setup_u = [&](int chunk, int slot) {
+        rs_u = pwc::make_rsrc(ug + (int64_t)chunk * uchunk, ubytes);
+        base_u = __builtin_amdgcn_readfirstlane(lds_u + slot * G::kUFloats * 4);
+    };
+    // transform unit t of this thread: (half, channel, tile); half 0 makes V rows 0,1, half 1 rows 2,3
+    f32x2 d[3][2];
+    float vo8[8];
+    auto unit_src = [&](int t, int rslot) -> const float * {
+        const int u = t * kThreads + tid;
+        const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, half = u / (128 * TG);
+        const int tgi = n >> 5, tile = n & 31;
+        return raw + rslot * G::kRawRegion + c * G::kRawPlane + (kGH * tgi + 2 * (tile >> 4) + half) * kRawW + 2 * (tile & 15);
+    };
+    auto unit_dst = [&](int t, int vslot) -> float * {
+        const int u = t * kThreads + tid;
+        const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, half = u / (128 * TG);
+        const int tgi = n >> 5, tile = n & 31;
+        return vbuf + vslot * G::kVFloats + ((tgi * 16 + half * 8) * 2 + (c & 1)) * 64 + tile * 2 + (c >> 1);
+    };
+    auto unit_load = [&](int t, int rslot) {
+        const float *p = unit_src(t, rslot);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            d[r][0] = *reinterpret_cast<const f32x2 *>(p + r * kRawW);
+            d[r][1] = *reinterpret_cast<const f32x2 *>(p + r * kRawW + 2);
+        }
+    };
+    auto unit_math = [&](int t) {
+        const int half = (t * kThreads + tid) / (128 * TG);
+        float w0[4], w1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float da = d[0][j >> 1][j & 1], db = d[1][j >> 1][j & 1], dc = d[2][j >> 1][j & 1];
+            // half 0: rows (d0,d1,d2): Bt rows 0,1 = d0-d2, d1+d2.   half 1: rows (d1,d2,d3): Bt rows 2,3 = d2-d1, d1-d3
+            w0[j] = half ? (db - da) : (da - dc);
+            w1[j] = half ? (da - dc) : (db + dc);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float *wr = i ? w1 : w0;
+            vo8[i * 4 + 0] = wr[0] - wr[2];
+            vo8[i * 4 + 1] = wr[1] + wr[2];
+            vo8[i * 4 + 2] = wr[2] - wr[1];
+            vo8[i * 4 + 3] = wr[1] - wr[3];
+        }
+    };
+    auto unit_store = [&](int t, int vslot, int lo) {
+        float *vo = unit_dst(t, vslot);
+#pragma unroll
+        for (int i = lo; i < lo + 4; ++i) vo[i * 128] = vo8[i];
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[p][j] = 0.f;
+
+    const int blk = wave % MT, tgw = wave / MT;
+    const int ua_off = (kh * G::kCoutT + blk * 32 + col) * 2;
+    const int vb_off = tgw * G::kVGroup + (kh * 32 + col) * 2;
+
+    // FULL: every piece of the iteration exists (k + 3 < nchunks); otherwise each piece is guarded
+    auto iteration = [&](int k, int r3, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        // slots of the rings: raw(k+3) -> r3 (= k % 3), raw(k+1) in (k+1) % 3; U(k) in k % 3, U(k+2) -> (k+2) % 3
+        const int r1 = (r3 == 2) ? 0 : r3 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
+        const bool do_raw = FULL || (k + 3 < nchunks), do_u = FULL || (k + 2 < nchunks), do_tr = FULL || (k + 1 < nchunks);
+        if (FULL || k + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RS + US) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (do_raw) setup_raw(k + 3, r3);
+        if (do_u) setup_u(k + 2, r2);
+        const float *ua = ubuf + r3 * G::kUFloats + ua_off;
+        const float *vb = vbuf + (k & 1) * G::kVFloats + vb_off;
+        f32x2 a2[2][4], b2[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a2[0][i] = *reinterpret_cast<const f32x2 *>(ua + i * (2 * G::kCoutT * 2));
+            b2[0][i] = *reinterpret_cast<const f32x2 *>(vb + i * 128);
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int q = s >> 3, i = s & 7;
+            if (i < 4 && q < 3) {
+                a2[(q + 1) & 1][i] = *reinterpret_cast<const f32x2 *>(ua + (4 * (q + 1) + i) * (2 * G::kCoutT * 2));
+                b2[(q + 1) & 1][i] = *reinterpret_cast<const f32x2 *>(vb + (4 * (q + 1) + i) * 128);
+            }
+            acc[4 * q + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[q & 1][i & 3][i >> 2], b2[q & 1][i & 3][i >> 2], acc[4 * q + (i & 3)], 0, 0, 0);
+            if (s < RS) {
+                if (do_raw) pwc::dma_b32(rs_raw, base_raw + s * kThreads * 4, raw_off[s]);
+            } else if (s < RS + US) {
+                if (do_u) pwc::dma_b128(rs_u, base_u + (s - RS) * kThreads * 16, u_off[s - RS]);
+            } else if (s - RS - US < 4 * TG) {
+                const int t = (s - RS - US) >> 2, ph = (s - RS - US) & 3;
+                if (do_tr) {
+                    if (ph == 0) unit_load(t, r1);
+                    else if (ph == 1) unit_math(t);
+                    else unit_store(t, (k + 1) & 1, (ph - 2) * 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // prologue: raw(0) -> V(0); then the two groups the loop expects in flight: {raw(1), U(0)} and {raw(2), U(1)}
+    setup_raw(0, 0);
+#pragma unroll
+    for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads * 4, raw_off[j]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        unit_load(t, 0);
+        unit_math(t);
+        unit_store(t, 0, 0);
+        unit_store(t, 0, 4);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+        if (gq + 1 < nchunks) {
+            setup_raw(gq + 1, gq + 1);
+#pragma unroll
+            for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads * 4, raw_off[j]);
+        }
+        if (gq < nchunks) {
+            setup_u(gq, gq);
+#pragma unroll
+            for (int j = 0; j < US; ++j) pwc::dma_b128(rs_u, base_u + j * kThreads * 16, u_off[j]);
+        }
+    }
+    int r3 = 0;
+    int k = 0;
+    for (; k + 3 < nchunks; ++k) {
+        iteration(k, r3, std::true_type{});
+        r3 = (r3 == 2) ? 0 : r3 + 1;
+    }
+    for (; k < nchunks; ++k) {
+        iteration(k, r3, std::false_type{});
+        r3 = (r3 == 2) ? 0 : r3 + 1;
+    }
+
+    // ---- output transform At M A in registers, bias, LeakyReLU, 8-byte stores --------------------------
+    const int oy = oy0 + kGH * tgw + 2 * (col >> 4);
+    const int ox = ox0 + 2 * (col & 15);
+    if (oy >= H || ox >= W) return;
+    const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int co = g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+        if (co >= Cout) continue;
+        float t0[4], t1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t0[c] = acc[c][j] + acc[4 + c][j] + acc[8 + c][j];
+            t1[c] = acc[4 + c][j] - acc[8 + c][j] - acc[12 + c][j];
+        }
+        const float bv = bias[co];
+        float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
+        float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
+        if (do_leaky) { y00 = leaky(y00, slope); y01 = leaky(y01, slope); y10 = leaky(y10, slope); y11 = leaky(y11, slope); }
+        float *o = y + obase + (int64_t)co * plane;
+        if (vec2) {
+            *reinterpret_cast<f32x2 *>(o) = (f32x2){y00, y01};
+            if (oy + 1 < H) *reinterpret_cast<f32x2 *>(o + W) = (f32x2){y10, y11};
+        } else {
+            o[0] = y00;
+            if (ox + 1 < W) o[1] = y01;
+            if (oy + 1 < H) {
+                o[W] = y10;
+                if (ox + 1 < W) o[W + 1] = y11;
+            }
+        }
+    }
+}
+
+inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
+
+template <int MT>
+int launch_wino(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout,
+                int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st) {
+    using G = Geo<MT>;
+    static pwc::LdsAttrOnce once;
+    if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino_kernel<MT>), G::kSmemBytes,
+                                            "conv3x3_wino_kernel"))
+        return rc;
+    const int CoutP = cout_padded(Cout);
+    const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kGH * G::kTG - 1) / (kGH * G::kTG);
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: grid too large");
+    const int vec2 = (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
+    hipLaunchKernelGGL(conv3x3_wino_kernel<MT>, dim3((unsigned)nblk, (unsigned)(CoutP / G::kCoutT)), dim3(kThreads), G::kSmemBytes, st,
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2);
+    pwc::note_kernel("conv3x3_wino_kernel", MT, G::kTG, 1, 1, 1, 0);
+    return pwc::check_launch("conv3x3_wino_kernel");
+}
+
+}  // namespace
+
+extern "C" int64_t pwc_conv3x3_wino_packed_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return -1;
+    return (int64_t)((Cin + kCK - 1) / kCK) * 64 * cout_padded(Cout) * (int64_t)sizeof(float);
+}
+
+extern "C" int pwc_conv3x3_wino_pack(const void *w, void *up, int Cin, int Cout, void *stream) {
+    if (!w || !up) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_pack: null pointer");
+    if (Cin <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_pack: bad shape");
+    if (!pwc::aligned16(up)) PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino_pack: packed buffer must be 16-byte aligned");
+    const int64_t total = pwc_conv3x3_wino_packed_bytes(Cin, Cout) / (int64_t)sizeof(float);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(w), static_cast<float *>(up), Cin, Cout, cout_padded(Cout), total);
+    return pwc::check_launch("wino_pack_kernel");
+}
+
+extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *y, int B, int Cin, int H, int W, int Cout,
+                                    unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
+    if (!x || !up || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: null pointer");
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: bad shape");
+    if (!pwc::aligned16(up)) PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino_fwd: packed filters must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 3u)
+        PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino_fwd: tensors must be 4-byte aligned");
+    const int64_t plane = (int64_t)H * W;
+    if (x_bstride < Cin * plane || y_bstride < Cout * plane) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: batch stride smaller than the tensor");
+    if (plane * kCK * 4 >= 0x7fffffffLL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv3x3_wino_fwd: image plane too large for 32-bit DMA offsets");
+    const float *xf = static_cast<const float *>(x), *uf = static_cast<const float *>(up), *bf = static_cast<const float *>(bias);
+    float *yf = static_cast<float *>(y);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
+    const int CoutP = cout_padded(Cout);
+    if (CoutP % 128 == 0) return launch_wino<4>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st);
+    if (CoutP % 64 == 0) return launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st);
+    return launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st);
+}

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Winograd F(2x2,3x3) convolution against the direct MFMA implicit GEMM: max error vs an fp64 reference on small cases,
+then level-2 layer timings at batch 16 (HIP events).  usage: bench_wino.py [check|time|all]"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from opticalflow_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+g = torch.Generator().manual_seed(0)
+
+
+def case(B, cin, cout, H, W, leaky=0.1):
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if leaky is not None:
+        ref = F.leaky_relu(ref, leaky)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    y = ops.conv3x3_wino(xd, ops.pack_conv3x3_wino(wd), bd, cout, leaky_slope=leaky)
+    y0 = ops.conv3x3(xd, ops.pack_conv3x3(wd), bd, cout, leaky_slope=leaky)
+    torch.cuda.synchronize()
+    e = (y.cpu().double() - ref).abs().max().item()
+    e0 = (y0.cpu().double() - ref).abs().max().item()
+    print("B%d %3d->%3d %3dx%3d: wino max err %.3e   direct %.3e   (|ref| max %.2f)" % (B, cin, cout, H, W, e, e0, ref.abs().max().item()), flush=True)
+    return e
+
+
+if mode in ("check", "all"):
+    for shp in ((1, 4, 32, 4, 32), (1, 8, 32, 8, 32), (2, 5, 7, 9, 13), (1, 16, 128, 12, 64), (2, 37, 96, 17, 70), (1, 64, 64, 20, 40), (1, 130, 128, 16, 33),
+                (1, 21, 40, 33, 31)):
+        case(*shp)
+    case(1, 12, 32, 10, 36, leaky=None)
+
+if mode in ("time", "all"):
+    B, H, W = 16, 112, 256
+
+    def t(fn, reps=10):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        e.synchronize()
+        return s.elapsed_time(e) / reps
+
+    for name, cin, cout in (("conv2_0", 117, 128), ("conv2_1", 245, 128), ("conv2_2", 373, 96), ("conv2_3", 469, 64), ("conv2_4", 533, 32), ("dc_conv1", 565, 128)):
+        x = torch.randn(B, cin, H, W, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.zeros(cout, device=dev)
+        up, wp = ops.pack_conv3x3_wino(w), ops.pack_conv3x3(w)
+        y, y0 = torch.empty(B, cout, H, W, device=dev), torch.empty(B, cout, H, W, device=dev)
+        tw = t(lambda: ops.conv3x3_wino(x, up, b, cout, out=y))
+        td = t(lambda: ops.conv3x3(x, wp, b, cout, out=y0))
+        gf = 2.0 * 9 * cin * cout * B * H * W / 1e9
+        print("%-9s %3d->%3d: wino %7.1f us (%.0f TF direct-equivalent)   direct %7.1f us (%.0f TF)   x%.2f   max diff %.2e" %
+              (name, cin, cout, tw * 1e3, gf / tw, td * 1e3, gf / td, td / tw, (y - y0).abs().max().item()), flush=True)
