@@ -16,6 +16,8 @@
 //                   raw(k+3) and U(k+2) and the transform raw(k+1) -> V(k+1)
 // LDS: raw [3][4][rows+2][34], U [3][16][2][32*MT][2], V [2][tile groups][16][2][32][2]  (98-124 KiB, one workgroup per CU).
 // Zero padding, ragged edges and the ragged last channel chunk come from the buffer range check (0 into LDS).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "pwc_common.h"
@@ -49,7 +51,7 @@ struct Geo {
     static constexpr int kSmemBytes = (3 * (kRawRegion + kUFloats) + 2 * kVFloats) * 4;         // raw, U: rings of 3; V: 2
 };
 
-// U[chunk][pos][kh][co][step] <- G g Gt of w[co][cin = chunk*4 + 2*step + kh], zero padded
+// U[chunk][pos][kh][co][step] <- G g Gt of w[co][cin = chunk*4 + 2*kh + step], zero padded
 __global__ void __launch_bounds__(256)
 wino_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, int Cout, int CoutP, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,7 +64,7 @@ wino_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, i
     t >>= 1;
     const int pos = (int)(t & 15);
     const int chunk = (int)(t >> 4);
-    const int cin = chunk * kCK + 2 * step + kh;
+    const int cin = chunk * kCK + 2 * kh + step;
     float v = 0.f;
     if (co < Cout && cin < Cin) {
         const float *g = w + ((int64_t)co * Cin + cin) * 9;
@@ -157,8 +159,8 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
         base_u = __builtin_amdgcn_readfirstlane(lds_u + slot * G::kUFloats * 4);
     };
     // transform unit t of this thread: (half, channel, tile); half 0 makes V rows 0,1, half 1 rows 2,3
-    f32x2 d[3][2];
-    float vo8[8];
+    f32x2 d[TG][3][2];
+    float vo8[TG][8];
     auto unit_src = [&](int t, int rslot) -> const float * {
         const int u = t * kThreads + tid;
         const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, half = u / (128 * TG);
@@ -169,14 +171,14 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
         const int u = t * kThreads + tid;
         const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, half = u / (128 * TG);
         const int tgi = n >> 5, tile = n & 31;
-        return vbuf + vslot * G::kVFloats + ((tgi * 16 + half * 8) * 2 + (c & 1)) * 64 + tile * 2 + (c >> 1);
+        return vbuf + vslot * G::kVFloats + ((tgi * 16 + half * 8) * 2 + (c >> 1)) * 64 + tile * 2 + (c & 1);
     };
     auto unit_load = [&](int t, int rslot) {
         const float *p = unit_src(t, rslot);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            d[r][0] = *reinterpret_cast<const f32x2 *>(p + r * kRawW);
-            d[r][1] = *reinterpret_cast<const f32x2 *>(p + r * kRawW + 2);
+            d[t][r][0] = *reinterpret_cast<const f32x2 *>(p + r * kRawW);
+            d[t][r][1] = *reinterpret_cast<const f32x2 *>(p + r * kRawW + 2);
         }
     };
     auto unit_math = [&](int t) {
@@ -184,7 +186,7 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
         float w0[4], w1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float da = d[0][j >> 1][j & 1], db = d[1][j >> 1][j & 1], dc = d[2][j >> 1][j & 1];
+            const float da = d[t][0][j >> 1][j & 1], db = d[t][1][j >> 1][j & 1], dc = d[t][2][j >> 1][j & 1];
             // half 0: rows (d0,d1,d2): Bt rows 0,1 = d0-d2, d1+d2.   half 1: rows (d1,d2,d3): Bt rows 2,3 = d2-d1, d1-d3
             w0[j] = half ? (db - da) : (da - dc);
             w1[j] = half ? (da - dc) : (db + dc);
@@ -192,16 +194,16 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float *wr = i ? w1 : w0;
-            vo8[i * 4 + 0] = wr[0] - wr[2];
-            vo8[i * 4 + 1] = wr[1] + wr[2];
-            vo8[i * 4 + 2] = wr[2] - wr[1];
-            vo8[i * 4 + 3] = wr[1] - wr[3];
+            vo8[t][i * 4 + 0] = wr[0] - wr[2];
+            vo8[t][i * 4 + 1] = wr[1] + wr[2];
+            vo8[t][i * 4 + 2] = wr[2] - wr[1];
+            vo8[t][i * 4 + 3] = wr[1] - wr[3];
         }
     };
     auto unit_store = [&](int t, int vslot, int lo) {
         float *vo = unit_dst(t, vslot);
 #pragma unroll
-        for (int i = lo; i < lo + 4; ++i) vo[i * 128] = vo8[i];
+        for (int i = lo; i < lo + 4; ++i) vo[i * 128] = vo8[t][i];
     };
 
     f32x16 acc[16];
@@ -214,7 +216,14 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
     const int ua_off = (kh * G::kCoutT + blk * 32 + col) * 2;
     const int vb_off = tgw * G::kVGroup + (kh * 32 + col) * 2;
 
-    // FULL: every piece of the iteration exists (k + 3 < nchunks); otherwise each piece is guarded
+    f32x2 a2[2][4], b2[2][4];                 // operand sets: groups 0, 2 use set 0; groups 1, 3 set 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a2[1][i] = b2[1][i] = (f32x2){0.f, 0.f};     // "group 3 of chunk -1" adds 0 * 0
+
+    // FULL: every piece of the iteration exists (k + 3 < nchunks); otherwise each piece is guarded.
+    // The iteration is rotated by one group: its first 8 MFMAs are positions 12..15 of chunk k-1, whose operands were read
+    // into registers before the barrier, so the matrix pipe restarts right behind the barrier while everything else of the
+    // iteration -- operand reads of chunk k, descriptors, LDS-DMA, transform -- issues in MFMA shadows.
     auto iteration = [&](int k, int r3, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         // slots of the rings: raw(k+3) -> r3 (= k % 3), raw(k+1) in (k+1) % 3; U(k) in k % 3, U(k+2) -> (k+2) % 3
@@ -223,34 +232,43 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
         if (FULL || k + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RS + US) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (do_raw) setup_raw(k + 3, r3);
-        if (do_u) setup_u(k + 2, r2);
         const float *ua = ubuf + r3 * G::kUFloats + ua_off;
         const float *vb = vbuf + (k & 1) * G::kVFloats + vb_off;
-        f32x2 a2[2][4], b2[2][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a2[0][i] = *reinterpret_cast<const f32x2 *>(ua + i * (2 * G::kCoutT * 2));
-            b2[0][i] = *reinterpret_cast<const f32x2 *>(vb + i * 128);
-        }
+        constexpr int kDma0 = 3;                                // first LDS-DMA slot (descriptors are built in slot 2)
+        constexpr int kTr0 = 4, kTrStep = (TG == 4) ? 6 : 8;    // unit t: loads in slot kTr0 + t*kTrStep, adds 2 later, writes 3 and 4 later
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            const int q = s >> 3, i = s & 7;
-            if (i < 4 && q < 3) {
+            const int q = (s >> 3) - 1, i = s & 7;              // q = -1: group 3 of the previous chunk (operand set 1)
+            const int pq = (q < 0) ? 3 : q;
+            acc[4 * pq + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[pq & 1][i & 3][i >> 2], b2[pq & 1][i & 3][i >> 2], acc[4 * pq + (i & 3)], 0, 0, 0);
+            if (s < 2) {                                        // operands of group 0 of this chunk
+#pragma unroll
+                for (int j = 2 * s; j < 2 * s + 2; ++j) {
+                    a2[0][j] = *reinterpret_cast<const f32x2 *>(ua + j * (2 * G::kCoutT * 2));
+                    b2[0][j] = *reinterpret_cast<const f32x2 *>(vb + j * 128);
+                }
+            }
+            if (i < 4 && q >= 0) {                              // operands of group q+1 during group q
                 a2[(q + 1) & 1][i] = *reinterpret_cast<const f32x2 *>(ua + (4 * (q + 1) + i) * (2 * G::kCoutT * 2));
                 b2[(q + 1) & 1][i] = *reinterpret_cast<const f32x2 *>(vb + (4 * (q + 1) + i) * 128);
             }
-            acc[4 * q + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[q & 1][i & 3][i >> 2], b2[q & 1][i & 3][i >> 2], acc[4 * q + (i & 3)], 0, 0, 0);
-            if (s < RS) {
-                if (do_raw) pwc::dma_b32(rs_raw, base_raw + s * kThreads * 4, raw_off[s]);
-            } else if (s < RS + US) {
-                if (do_u) pwc::dma_b128(rs_u, base_u + (s - RS) * kThreads * 16, u_off[s - RS]);
-            } else if (s - RS - US < 4 * TG) {
-                const int t = (s - RS - US) >> 2, ph = (s - RS - US) & 3;
-                if (do_tr) {
+            if (s == 2) {
+                if (do_raw) setup_raw(k + 3, r3);
+                if (do_u) setup_u(k + 2, r2);
+            }
+            if (s >= kDma0 && s < kDma0 + RS) {
+                if (do_raw) pwc::dma_b32(rs_raw, base_raw + (s - kDma0) * kThreads * 4, raw_off[s - kDma0]);
+            } else if (s >= kDma0 + RS && s < kDma0 + RS + US) {
+                if (do_u) pwc::dma_b128(rs_u, base_u + (s - kDma0 - RS) * kThreads * 16, u_off[s - kDma0 - RS]);
+            }
+            if (do_tr) {
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const int ph = s - kTr0 - t * kTrStep;
                     if (ph == 0) unit_load(t, r1);
-                    else if (ph == 1) unit_math(t);
-                    else unit_store(t, (k + 1) & 1, (ph - 2) * 4);
+                    else if (ph == 2) unit_math(t);
+                    else if (ph == 3) unit_store(t, (k + 1) & 1, 0);
+                    else if (ph == 4) unit_store(t, (k + 1) & 1, 4);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -293,12 +311,18 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
         iteration(k, r3, std::false_type{});
         r3 = (r3 == 2) ? 0 : r3 + 1;
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)               // group 3 of the last chunk
+        acc[12 + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][i & 3][i >> 2], b2[1][i & 3][i >> 2], acc[12 + (i & 3)], 0, 0, 0);
 
     // ---- output transform At M A in registers, bias, LeakyReLU, 8-byte stores --------------------------
     const int oy = oy0 + kGH * tgw + 2 * (col >> 4);
     const int ox = ox0 + 2 * (col & 15);
     if (oy >= H || ox >= W) return;
     const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
+    float bvs[16];                            // one batch of loads, one wait (16 dependent round trips otherwise)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bvs[j] = bias[min(g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int co = g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
@@ -309,7 +333,7 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
             t0[c] = acc[c][j] + acc[4 + c][j] + acc[8 + c][j];
             t1[c] = acc[4 + c][j] - acc[8 + c][j] - acc[12 + c][j];
         }
-        const float bv = bias[co];
+        const float bv = bvs[j];
         float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
         float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
         if (do_leaky) { y00 = leaky(y00, slope); y01 = leaky(y01, slope); y10 = leaky(y10, slope); y11 = leaky(y11, slope); }

@@ -38,6 +38,18 @@ if mode in ("check", "all"):
         case(*shp)
     case(1, 12, 32, 10, 36, leaky=None)
 
+if mode == "pmc":          # one layer, few launches, for the counter passes of tools/pmc_wino.sh
+    B, H, W, cin, cout = 16, 112, 256, 565, 128
+    x = torch.randn(B, cin, H, W, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.zeros(cout, device=dev)
+    up, wp = ops.pack_conv3x3_wino(w), ops.pack_conv3x3(w)
+    y = torch.empty(B, cout, H, W, device=dev)
+    for _ in range(4):
+        ops.conv3x3_wino(x, up, b, cout, out=y)
+        ops.conv3x3(x, wp, b, cout, out=y)
+    torch.cuda.synchronize()
+
 if mode in ("time", "all"):
     B, H, W = 16, 112, 256
 
