@@ -150,6 +150,8 @@ int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int s
  * up = pwc_conv3x3_wino_pack(w) holds G g Gt per (cout, cin) in the kernel's LDS order [chunk of 4 cin][16][2][CoutP][2].
  * x:[B,Cin,H,W], y:[B,Cout,H,W] with free batch strides (elements); flags: PWC_ACT_LEAKY only. */
 int64_t pwc_conv3x3_wino_packed_bytes(int Cin, int Cout);
+/* 1 when this route is expected to beat pwc_conv2d_fwd for the layer (enough workgroups for 256 CUs, Cout >= 32), else 0 */
+int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout);
 int pwc_conv3x3_wino_pack(const void *w, void *up, int Cin, int Cout, void *stream);
 int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *y,
                          int B, int Cin, int H, int W, int Cout, unsigned flags, float leaky_slope,

@@ -375,6 +375,16 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
 
 }  // namespace
 
+// Does the Winograd route beat pwc_conv2d_fwd for this layer?  Measured rule (tools/bench_wino.py layers, batch 16): it needs
+// enough workgroups to cover the 256 CUs (one workgroup per CU, 4 waves) and at least one full 32-row cout block.
+extern "C" int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout) {
+    if (B <= 0 || Cin < 16 || H <= 0 || W <= 0 || Cout < 32) return 0;
+    const int CoutP = cout_padded(Cout);
+    const int mt = (CoutP % 128 == 0) ? 4 : (CoutP % 64 == 0) ? 2 : 1;
+    const int64_t nwg = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + kGH * (4 / mt) - 1) / (kGH * (4 / mt))) * (CoutP / (32 * mt));
+    return nwg >= 160;
+}
+
 extern "C" int64_t pwc_conv3x3_wino_packed_bytes(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return -1;
     return (int64_t)((Cin + kCK - 1) / kCK) * 64 * cout_padded(Cout) * (int64_t)sizeof(float);

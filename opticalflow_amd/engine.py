@@ -125,11 +125,16 @@ class PwcPlan:
         self.ctx = [torch.empty((B, c, h2, w2), **kw) for c, _ in CONTEXT]
 
         self.packed: Dict[str, torch.Tensor] = {}
+        self.wino_packed: Dict[str, torch.Tensor] = {}
+        self.wino = os.environ.get("PWC_CONV_WINO", "1") != "0" and dtype == torch.float32
         self.workspace: Optional[torch.Tensor] = None
         if conv_backend == "hip":
             for key, t in self.p.items():
                 if key.endswith(".weight") and t.dim() == 4 and t.shape[2:] == (3, 3):
                     self.packed[key[:-len(".weight")]] = ops.pack_conv3x3(t)
+                    # G g Gt for every layer the Winograd route could take (67 MB for the whole net): nothing is allocated later
+                    if self.wino and t.shape[0] >= 32 and t.shape[1] >= 16:
+                        self.wino_packed[key[:-len(".weight")]] = ops.pack_conv3x3_wino(t)
             # one split-K scratch shared by every stride-1 conv of the decoder (they run back to back on one stream)
             need = 0
             for l in range(2, 7):
@@ -155,6 +160,11 @@ class PwcPlan:
               act: bool = True, residual: Optional[torch.Tensor] = None) -> None:
         key = name + ".0" if (name + ".0.weight") in self.p else name
         w, b = self.p[key + ".weight"], self.p[key + ".bias"]
+        if (self.wino and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and dilation == 1 and residual is None and x.dtype == torch.float32
+                and ops.conv3x3_wino_preferred(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0])):
+            # Winograd F(2x2,3x3) on the matrix cores: 2.25x fewer MFMA passes for the same fp32 convolution
+            ops.conv3x3_wino(x, self.wino_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out)
+            return
         if self.conv_backend == "hip":
             ops.conv3x3(x, self.packed[key], b, w.shape[0], stride=stride, dilation=dilation,
                         leaky_slope=LEAKY if act else None, residual=residual, out=out, workspace=self.workspace)

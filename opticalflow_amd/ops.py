@@ -271,6 +271,11 @@ def conv3x3(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cout: in
     return out
 
 
+def conv3x3_wino_preferred(B: int, cin: int, H: int, W: int, cout: int) -> bool:
+    """Whether the Winograd route is expected to beat conv3x3 for this stride-1 / dilation-1 layer (rule lives in the library)."""
+    return bool(_lib.load().pwc_conv3x3_wino_preferred(B, cin, H, W, cout))
+
+
 def pack_conv3x3_wino(weight: torch.Tensor) -> torch.Tensor:
     """[Cout,Cin,3,3] filter bank -> Winograd F(2x2,3x3) filters G g Gt in the kernel's LDS order (device, float32)."""
     lib = _lib.load()

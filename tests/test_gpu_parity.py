@@ -661,3 +661,78 @@ def test_forward_full_size_batch16(dev):
         fs = net(same)
         assert all(torch.equal(fs[0], fs[i]) for i in range(1, 16))
         assert torch.equal(fs[0].cpu(), f[0])
+
+
+# ---- Winograd F(2x2,3x3) route of the 3x3 convolution (pwc_conv3x3_wino_fwd) ------------------------------------------
+WINO_CASES = [  # B, Cin, Cout, H, W
+    (1, 4, 32, 4, 32),        # one tile group, one chunk
+    (2, 5, 7, 9, 13),         # ragged everything: Cin % 4, Cout < 32, odd H and W (scalar stores)
+    (1, 16, 128, 12, 64),     # MT=4
+    (2, 37, 96, 17, 70),      # MT=1 x 3 cout groups, ragged chunk
+    (1, 64, 64, 20, 40),      # MT=2
+    (1, 130, 128, 16, 33),    # long K, odd W
+    (3, 21, 40, 33, 31),      # CoutP = 64 with 24 padded rows
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd_vs_fp64(gpu_device, case):
+    """Same operator as conv3x3 (nn.Conv2d 3x3 pad 1 + LeakyReLU, PWCNet.py:26-33); the bound is the direct kernel's own:
+    3e-6 * sqrt(9 Cin) of unit-scale data (the Winograd transforms only add, the accumulation is 2.25x shorter)."""
+    from opticalflow_amd import ops
+    B, cin, cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1)
+    xd, wd, bd = x.to(gpu_device), w.to(gpu_device), b.to(gpu_device)
+    up = ops.pack_conv3x3_wino(wd)
+    got = ops.conv3x3_wino(xd, up, bd, cout).cpu()
+    tol = 3e-6 * (cin * 9) ** 0.5
+    assert (got.double() - ref).abs().max().item() <= tol
+    # no activation, and agreement with the direct MFMA kernel to the same bound
+    lin = ops.conv3x3_wino(xd, up, bd, cout, leaky_slope=None).cpu()
+    direct = ops.conv3x3(xd, ops.pack_conv3x3(wd), bd, cout, leaky_slope=None).cpu()
+    assert (lin - direct).abs().max().item() <= 2 * tol
+
+
+@pytest.mark.gpu
+def test_conv3x3_winograd_arena_views_and_errors(gpu_device):
+    """Channel-slice views of a wider arena on both sides (free batch strides), as the decoder uses them; argument errors."""
+    from opticalflow_amd import ops
+    g = torch.Generator().manual_seed(5)
+    arena = torch.randn(2, 50, 12, 36, generator=g).to(gpu_device)
+    w = (torch.randn(32, 20, 3, 3, generator=g) * 0.1).to(gpu_device)
+    b = torch.zeros(32, device=gpu_device)
+    x = arena[:, 30:50]
+    out_arena = torch.full((2, 40, 12, 36), 7.0, device=gpu_device)
+    up = ops.pack_conv3x3_wino(w)
+    ops.conv3x3_wino(x, up, b, 32, out=out_arena[:, 4:36])
+    ref = F.leaky_relu(F.conv2d(x.contiguous(), w, b, padding=1), 0.1)
+    assert torch.allclose(out_arena[:, 4:36], ref, rtol=1e-5, atol=2e-5)
+    assert bool((out_arena[:, :4] == 7.0).all()) and bool((out_arena[:, 36:] == 7.0).all())      # neighbours untouched
+    with pytest.raises(ValueError):
+        ops.conv3x3_wino(x, up[:-4], b, 32)
+    with pytest.raises(ValueError):
+        ops.conv3x3_wino(x, up, b[:-1], 32)
+    assert ops.conv3x3_wino_preferred(16, 565, 112, 256, 128) and not ops.conv3x3_wino_preferred(16, 497, 7, 16, 32)
+
+
+@pytest.mark.gpu
+def test_forward_winograd_route_matches_direct_route(gpu_device, monkeypatch):
+    """The whole fp32 forward with the Winograd layers against the same forward on the direct kernels (PWC_CONV_WINO=0)."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    x = torch.rand(2, 6, 256, 512, generator=torch.Generator().manual_seed(11)).to(gpu_device)
+    flows = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PWC_CONV_WINO", flag)
+        net = PWCDCNet()
+        net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
+        net = net.to(gpu_device).eval()
+        flows[flag] = net(x).clone()
+        assert bool(net._plan_for(x).wino) == (flag == "1")
+    epe = (flows["1"] - flows["0"]).pow(2).sum(1).sqrt().mean().item()
+    assert epe < 2e-5, epe

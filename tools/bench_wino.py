@@ -50,6 +50,43 @@ if mode == "pmc":          # one layer, few launches, for the counter passes of 
         ops.conv3x3(x, wp, b, cout, out=y)
     torch.cuda.synchronize()
 
+if mode == "layers":       # every stride-1 / dilation-1 3x3 layer of the forward at batch 16 (pyramid: 32 images)
+    def t2(fn, reps=8):
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        s_.record()
+        for _ in range(reps):
+            fn()
+        e_.record()
+        e_.synchronize()
+        return s_.elapsed_time(e_) / reps
+
+    B0 = int(os.environ.get("PWC_BENCH_BATCH", "16"))
+    layers = []
+    pyr = {1: 16, 2: 32, 3: 64, 4: 96, 5: 128, 6: 196}
+    for l in range(1, 7):
+        layers.append(("conv%daa/b" % l, 2 * B0, pyr[l], pyr[l], 448 >> l, 1024 >> l))
+    for l in range(6, 1, -1):
+        cin = 81 + (0 if l == 6 else pyr[l] + 4)
+        for i, co in enumerate((128, 128, 96, 64, 32)):
+            layers.append(("conv%d_%d" % (l, i), B0, cin, co, 448 >> l, 1024 >> l))
+            cin += co
+    layers.append(("dc_conv1", B0, 565, 128, 112, 256))
+    layers.append(("dc_conv6", B0, 64, 32, 112, 256))
+    for name, B, cin, cout, H, W in layers:
+        x = torch.randn(B, cin, H, W, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.zeros(cout, device=dev)
+        up, wp = ops.pack_conv3x3_wino(w), ops.pack_conv3x3(w)
+        y, y0 = torch.empty(B, cout, H, W, device=dev), torch.empty(B, cout, H, W, device=dev)
+        nws = ops.conv3x3_workspace_bytes(B, cin, H, W, cout)
+        ws = torch.empty(max(nws, 4) // 4, device=dev)
+        tw = t2(lambda: ops.conv3x3_wino(x, up, b, cout, out=y))
+        td = t2(lambda: ops.conv3x3(x, wp, b, cout, out=y0, workspace=ws if nws else None))
+        print("%-10s B%-2d %3d->%3d @%3dx%-3d: wino %7.1f us   direct %7.1f us   x%.2f" % (name, B, cin, cout, H, W, tw * 1e3, td * 1e3, td / tw), flush=True)
+
 if mode in ("time", "all"):
     B, H, W = 16, 112, 256
 
