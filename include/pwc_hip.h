@@ -144,17 +144,18 @@ int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, const void *
 /* Bytes of workspace the split-K route of this layer needs (0: the layer never splits; <0: bad shape). */
 int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation);
 
-/* ---- Winograd F(2x2,3x3) route of the same operator (nn.Conv2d 3x3, stride 1, padding 1, dilation 1 + LeakyReLU,
+/* ---- Winograd F(2x2,3x3) route of the same operator (nn.Conv2d 3x3, stride 1, padding = dilation + LeakyReLU,
  * PWCNet.py:26-33), fp32 in / fp32 MFMA accumulation / fp32 out: 16 multiplications per 2x2 outputs instead of 36.
  * The result differs from pwc_conv2d_fwd only by fp32 rounding (the transforms add and halve; tests bound it).
  * up = pwc_conv3x3_wino_pack(w) holds G g Gt per (cout, cin) in the kernel's LDS order [chunk of 4 cin][16][2][CoutP][2].
+ * A dilated layer runs as dilation^2 ordinary convolutions on the pixel lattices (y mod D, x mod D).
  * x:[B,Cin,H,W], y:[B,Cout,H,W] with free batch strides (elements); flags: PWC_ACT_LEAKY only. */
 int64_t pwc_conv3x3_wino_packed_bytes(int Cin, int Cout);
 /* 1 when this route is expected to beat pwc_conv2d_fwd for the layer (enough workgroups for 256 CUs, Cout >= 32), else 0 */
-int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout);
+int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout, int dilation);
 int pwc_conv3x3_wino_pack(const void *w, void *up, int Cin, int Cout, void *stream);
 int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *y,
-                         int B, int Cin, int H, int W, int Cout, unsigned flags, float leaky_slope,
+                         int B, int Cin, int H, int W, int Cout, int dilation, unsigned flags, float leaky_slope,
                          int64_t x_bstride, int64_t y_bstride, void *stream);
 
 /* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------

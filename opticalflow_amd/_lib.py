@@ -48,9 +48,9 @@ SIGNATURES = {
     "pwc_conv3x3_f16_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pwc_conv3x3_f16_pack_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pwc_conv3x3_wino_packed_bytes": (c_int64, [c_int, c_int]),
-    "pwc_conv3x3_wino_preferred": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "pwc_conv3x3_wino_preferred": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pwc_conv3x3_wino_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "pwc_conv3x3_wino_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
+    "pwc_conv3x3_wino_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
                              c_int64, c_int64, c_void_p]),
     "pwc_conv2d_f16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),

@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / dilation 1 convolution by Winograd F(2x2,3x3) on the gfx950 matrix cores, fp32 throughout.
+// 3x3 / stride 1 convolution (any dilation, padding = dilation) by Winograd F(2x2,3x3) on the gfx950 matrix cores, fp32 throughout.
 // Replaces nn.Conv2d(3x3, padding 1) + LeakyReLU(0.1) (reference models/PWCNet.py:26-33) for the large dense-block and
 // context layers: 16 multiplications per 2x2 outputs instead of 36, i.e. 2.25x fewer MFMA passes than the direct implicit
 // GEMM of pwc_conv_mfma.h for the same fp32 result (up to rounding: the transforms only add and halve).
@@ -88,7 +88,7 @@ template <int MT>
 __global__ void __launch_bounds__(kThreads, 1)
 conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                     float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                    int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2) {
+                    int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil) {
     using G = Geo<MT>;
     constexpr int TG = G::kTG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -105,6 +105,12 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
     int bid = blockIdx.x;
     // workgroups i, i+8, ... share an XCD: give each XCD a contiguous run of tiles so that halo re-reads hit its L2
     if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    // dilation D: the pixels with (y mod D, x mod D) = (ry, rx) form a lattice on which the layer is an ordinary 3x3
+    // convolution; a workgroup works on one such lattice (innermost in the block index, so the D*D lattices of a region
+    // run together on one XCD) and only its global addresses know about D.  All tile coordinates below are lattice coordinates.
+    const int sub = bid % (dil * dil);
+    bid /= dil * dil;
+    const int ry = sub / dil, rx = sub % dil;
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
@@ -121,8 +127,8 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
         const int i = j * kThreads + tid;
         const int c = i / G::kRawPlane;
         const int rem = i % G::kRawPlane;
-        const int iy = oy0 - 1 + rem / kRawW;
-        const int ix = ox0 - 1 + rem % kRawW;
+        const int iy = ry + dil * (oy0 - 1 + rem / kRawW);
+        const int ix = rx + dil * (ox0 - 1 + rem % kRawW);
         const bool ok = (i < G::kRawElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
         raw_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
     }
@@ -316,8 +322,8 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
         acc[12 + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][i & 3][i >> 2], b2[1][i & 3][i >> 2], acc[12 + (i & 3)], 0, 0, 0);
 
     // ---- output transform At M A in registers, bias, LeakyReLU, 8-byte stores --------------------------
-    const int oy = oy0 + kGH * tgw + 2 * (col >> 4);
-    const int ox = ox0 + 2 * (col & 15);
+    const int oy = ry + dil * (oy0 + kGH * tgw + 2 * (col >> 4));
+    const int ox = rx + dil * (ox0 + 2 * (col & 15));
     if (oy >= H || ox >= W) return;
     const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
     float bvs[16];                            // one batch of loads, one wait (16 dependent round trips otherwise)
@@ -343,10 +349,10 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
             if (oy + 1 < H) *reinterpret_cast<f32x2 *>(o + W) = (f32x2){y10, y11};
         } else {
             o[0] = y00;
-            if (ox + 1 < W) o[1] = y01;
-            if (oy + 1 < H) {
-                o[W] = y10;
-                if (ox + 1 < W) o[W + 1] = y11;
+            if (ox + dil < W) o[dil] = y01;
+            if (oy + dil < H) {
+                o[(int64_t)dil * W] = y10;
+                if (ox + dil < W) o[(int64_t)dil * W + dil] = y11;
             }
         }
     }
@@ -355,7 +361,7 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
 inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
 
 template <int MT>
-int launch_wino(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout,
+int launch_wino(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int dil,
                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st) {
     using G = Geo<MT>;
     static pwc::LdsAttrOnce once;
@@ -363,26 +369,32 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
                                             "conv3x3_wino_kernel"))
         return rc;
     const int CoutP = cout_padded(Cout);
-    const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kGH * G::kTG - 1) / (kGH * G::kTG);
-    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    const int Hs = (H + dil - 1) / dil, Ws = (W + dil - 1) / dil;            // the largest of the D*D lattices
+    const int tiles_x = (Ws + kTW - 1) / kTW, tiles_y = (Hs + kGH * G::kTG - 1) / (kGH * G::kTG);
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y * dil * dil;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: grid too large");
-    const int vec2 = (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
+    const int vec2 = dil == 1 && (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
     hipLaunchKernelGGL(conv3x3_wino_kernel<MT>, dim3((unsigned)nblk, (unsigned)(CoutP / G::kCoutT)), dim3(kThreads), G::kSmemBytes, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2);
-    pwc::note_kernel("conv3x3_wino_kernel", MT, G::kTG, 1, 1, 1, 0);
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil);
+    pwc::note_kernel("conv3x3_wino_kernel", MT, G::kTG, 1, dil, 1, 0);
     return pwc::check_launch("conv3x3_wino_kernel");
 }
 
 }  // namespace
 
 // Does the Winograd route beat pwc_conv2d_fwd for this layer?  Measured rule (tools/bench_wino.py layers, batch 16): it needs
-// enough workgroups to cover the 256 CUs (one workgroup per CU, 4 waves) and at least one full 32-row cout block.
-extern "C" int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout) {
-    if (B <= 0 || Cin < 16 || H <= 0 || W <= 0 || Cout < 32) return 0;
+// enough workgroups to cover the 256 CUs (one workgroup per CU, 4 waves), at least one full 32-row cout block, and -- with
+// dilation D, where it runs on the D*D pixel lattices of ceil(H/D) x ceil(W/D) -- tiles that are mostly inside the lattice.
+extern "C" int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout, int dilation) {
+    if (B <= 0 || Cin < 16 || H <= 0 || W <= 0 || Cout < 32 || dilation < 1 || dilation > 8) return 0;
     const int CoutP = cout_padded(Cout);
     const int mt = (CoutP % 128 == 0) ? 4 : (CoutP % 64 == 0) ? 2 : 1;
-    const int64_t nwg = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + kGH * (4 / mt) - 1) / (kGH * (4 / mt))) * (CoutP / (32 * mt));
-    return nwg >= 160;
+    const int gh = kGH * (4 / mt);
+    const int Hs = (H + dilation - 1) / dilation, Ws = (W + dilation - 1) / dilation;
+    const int tiles_x = (Ws + kTW - 1) / kTW, tiles_y = (Hs + gh - 1) / gh;
+    const int64_t nwg = (int64_t)B * tiles_x * tiles_y * dilation * dilation * (CoutP / (32 * mt));
+    const double fill = (double)Hs * Ws / ((double)tiles_y * gh * tiles_x * kTW);
+    return nwg >= 160 && fill >= 0.7;
 }
 
 extern "C" int64_t pwc_conv3x3_wino_packed_bytes(int Cin, int Cout) {
@@ -401,9 +413,10 @@ extern "C" int pwc_conv3x3_wino_pack(const void *w, void *up, int Cin, int Cout,
 }
 
 extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *y, int B, int Cin, int H, int W, int Cout,
-                                    unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
+                                    int dilation, unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
     if (!x || !up || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: null pointer");
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: bad shape");
+    if (dilation < 1 || dilation > 64) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: dilation %d", dilation);
     if (!pwc::aligned16(up)) PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino_fwd: packed filters must be 16-byte aligned");
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 3u)
         PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino_fwd: tensors must be 4-byte aligned");
@@ -415,7 +428,7 @@ extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *b
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
     const int CoutP = cout_padded(Cout);
-    if (CoutP % 128 == 0) return launch_wino<4>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st);
-    if (CoutP % 64 == 0) return launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st);
-    return launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st);
+    if (CoutP % 128 == 0) return launch_wino<4>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st);
+    if (CoutP % 64 == 0) return launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st);
+    return launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st);
 }

@@ -126,6 +126,7 @@ class PwcPlan:
 
         self.packed: Dict[str, torch.Tensor] = {}
         self.wino_packed: Dict[str, torch.Tensor] = {}
+        self.conv_macs = {"direct": 0, "executed": 0}
         self.wino = os.environ.get("PWC_CONV_WINO", "1") != "0" and dtype == torch.float32
         self.workspace: Optional[torch.Tensor] = None
         if conv_backend == "hip":
@@ -160,11 +161,15 @@ class PwcPlan:
               act: bool = True, residual: Optional[torch.Tensor] = None) -> None:
         key = name + ".0" if (name + ".0.weight") in self.p else name
         w, b = self.p[key + ".weight"], self.p[key + ".bias"]
-        if (self.wino and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and dilation == 1 and residual is None and x.dtype == torch.float32
-                and ops.conv3x3_wino_preferred(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0])):
+        macs = x.shape[0] * w.shape[0] * w.shape[1] * 9 * ((x.shape[2] - 1) // stride + 1) * ((x.shape[3] - 1) // stride + 1)
+        self.conv_macs["direct"] += macs                          # what the layer costs as a direct convolution
+        if (self.wino and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and residual is None and x.dtype == torch.float32
+                and ops.conv3x3_wino_preferred(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], dilation)):
             # Winograd F(2x2,3x3) on the matrix cores: 2.25x fewer MFMA passes for the same fp32 convolution
-            ops.conv3x3_wino(x, self.wino_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out)
+            ops.conv3x3_wino(x, self.wino_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out, dilation=dilation)
+            self.conv_macs["executed"] += macs * 16 // 36         # multiplications the matrix cores actually perform
             return
+        self.conv_macs["executed"] += macs
         if self.conv_backend == "hip":
             ops.conv3x3(x, self.packed[key], b, w.shape[0], stride=stride, dilation=dilation,
                         leaky_slope=LEAKY if act else None, residual=residual, out=out, workspace=self.workspace)
@@ -191,6 +196,7 @@ class PwcPlan:
             raise ValueError("plan built for %s %s on %s, got %s %s on %s" % (
                 (B, 6, self.H, self.W), self.dtype, self.device, tuple(x.shape), x.dtype, x.device))
         x = ops.densify(x)
+        self.conv_macs = {"direct": 0, "executed": 0}           # 3x3 layers of this run (bench.py: utilisation of the matrix cores)
         # -- feature pyramid, both images as one 2B batch (PWCNet.py:184-195) ----------------------
         self._pyramid([(x[:, :3], 0, B), (x[:, 3:], B, 2 * B)], 0, 2 * B)
         return self._decode()

@@ -271,9 +271,9 @@ def conv3x3(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cout: in
     return out
 
 
-def conv3x3_wino_preferred(B: int, cin: int, H: int, W: int, cout: int) -> bool:
-    """Whether the Winograd route is expected to beat conv3x3 for this stride-1 / dilation-1 layer (rule lives in the library)."""
-    return bool(_lib.load().pwc_conv3x3_wino_preferred(B, cin, H, W, cout))
+def conv3x3_wino_preferred(B: int, cin: int, H: int, W: int, cout: int, dilation: int = 1) -> bool:
+    """Whether the Winograd route is expected to beat conv3x3 for this stride-1 layer (rule lives in the library)."""
+    return bool(_lib.load().pwc_conv3x3_wino_preferred(B, cin, H, W, cout, dilation))
 
 
 def pack_conv3x3_wino(weight: torch.Tensor) -> torch.Tensor:
@@ -293,8 +293,8 @@ def pack_conv3x3_wino(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_wino(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cout: int, leaky_slope: Optional[float] = 0.1,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """3x3 / stride 1 / dilation 1 convolution + bias (+ LeakyReLU) by Winograd F(2x2,3x3) on the matrix cores (fp32)."""
+                 out: Optional[torch.Tensor] = None, dilation: int = 1) -> torch.Tensor:
+    """3x3 / stride 1 convolution (padding = dilation) + bias (+ LeakyReLU) by Winograd F(2x2,3x3) on the matrix cores (fp32)."""
     lib = _lib.load()
     bsx = _plane_dense(x, "x")
     B, cin, H, W = x.shape
@@ -311,7 +311,7 @@ def conv3x3_wino(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cou
     if bias.dtype != torch.float32 or bias.numel() != cout or bias.device != x.device or not bias.is_contiguous():
         raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
     with torch.cuda.device(x.device):
-        rc = lib.pwc_conv3x3_wino_fwd(x.data_ptr(), upacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout,
+        rc = lib.pwc_conv3x3_wino_fwd(x.data_ptr(), upacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout, dilation,
                                       FLAG_ACT_LEAKY if leaky_slope is not None else 0, float(leaky_slope or 0.0), bsx, bsy, _stream(x))
     check(rc, "pwc_conv3x3_wino_fwd")
     return out

@@ -718,6 +718,23 @@ def test_conv3x3_winograd_arena_views_and_errors(gpu_device):
     with pytest.raises(ValueError):
         ops.conv3x3_wino(x, up, b[:-1], 32)
     assert ops.conv3x3_wino_preferred(16, 565, 112, 256, 128) and not ops.conv3x3_wino_preferred(16, 497, 7, 16, 32)
+    assert ops.conv3x3_wino_preferred(16, 128, 112, 256, 128, 4) and not ops.conv3x3_wino_preferred(16, 96, 112, 256, 64, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 8, 32, 16, 40, 2), (2, 20, 40, 23, 37, 2), (1, 16, 128, 40, 72, 4), (1, 12, 64, 33, 50, 8), (1, 9, 32, 20, 36, 3)])
+def test_conv3x3_winograd_dilated_vs_fp64(gpu_device, case):
+    """Dilated layers (dc_conv2..4, PWCNet.py:120-125: padding = dilation) run as D*D lattice convolutions; ragged lattices
+    (H, W not multiples of D) and every residue class are covered."""
+    from opticalflow_amd import ops
+    B, cin, cout, H, W, D = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=D, dilation=D), 0.1)
+    got = ops.conv3x3_wino(x.to(gpu_device), ops.pack_conv3x3_wino(w.to(gpu_device)), b.to(gpu_device), cout, dilation=D).cpu()
+    assert (got.double() - ref).abs().max().item() <= 3e-6 * (cin * 9) ** 0.5
 
 
 @pytest.mark.gpu

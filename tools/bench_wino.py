@@ -75,7 +75,12 @@ if mode == "layers":       # every stride-1 / dilation-1 3x3 layer of the forwar
             cin += co
     layers.append(("dc_conv1", B0, 565, 128, 112, 256))
     layers.append(("dc_conv6", B0, 64, 32, 112, 256))
-    for name, B, cin, cout, H, W in layers:
+    layers = [l + (1,) for l in layers] + [("dc_conv2 d2", B0, 128, 128, 112, 256, 2), ("dc_conv3 d4", B0, 128, 128, 112, 256, 4),
+                                           ("dc_conv4 d8", B0, 128, 96, 112, 256, 8), ("dc_conv5 d16", B0, 96, 64, 112, 256, 16)]
+    only = os.environ.get("PWC_BENCH_ONLY")
+    for name, B, cin, cout, H, W, D in layers:
+        if only and only not in name:
+            continue
         x = torch.randn(B, cin, H, W, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (cin * 9)) ** 0.5
         b = torch.zeros(cout, device=dev)
@@ -83,9 +88,10 @@ if mode == "layers":       # every stride-1 / dilation-1 3x3 layer of the forwar
         y, y0 = torch.empty(B, cout, H, W, device=dev), torch.empty(B, cout, H, W, device=dev)
         nws = ops.conv3x3_workspace_bytes(B, cin, H, W, cout)
         ws = torch.empty(max(nws, 4) // 4, device=dev)
-        tw = t2(lambda: ops.conv3x3_wino(x, up, b, cout, out=y))
-        td = t2(lambda: ops.conv3x3(x, wp, b, cout, out=y0, workspace=ws if nws else None))
-        print("%-10s B%-2d %3d->%3d @%3dx%-3d: wino %7.1f us   direct %7.1f us   x%.2f" % (name, B, cin, cout, H, W, tw * 1e3, td * 1e3, td / tw), flush=True)
+        tw = t2(lambda: ops.conv3x3_wino(x, up, b, cout, out=y, dilation=D))
+        td = t2(lambda: ops.conv3x3(x, wp, b, cout, dilation=D, out=y0, workspace=ws if (nws and D == 1) else None))
+        print("%-12s B%-2d %3d->%3d @%3dx%-3d: wino %7.1f us   direct %7.1f us   x%.2f   preferred=%d   max diff %.1e" %
+              (name, B, cin, cout, H, W, tw * 1e3, td * 1e3, td / tw, ops.conv3x3_wino_preferred(B, cin, H, W, cout, D), (y - y0).abs().max().item()), flush=True)
 
 if mode in ("time", "all"):
     B, H, W = 16, 112, 256

@@ -29,6 +29,9 @@ cp "$ROOT/gpurun_out/tl/kernel_stats_fp16.csv" "$OUT/f16_kernel_stats_bench_b16.
 say "dominant kernels alone (rocprofv3 averages): dc_conv1 fp32 / fp16, fused warp+corr, backward kernels"
 rocprofv3 --kernel-trace --stats -d "$OUT/p1" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv.py" dc_conv1 > "$OUT/microbench_dc_conv1.txt" 2>&1
 cp "$(find "$OUT/p1" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_dc_conv1.csv"; rm -rf "$OUT/p1"
+rocprofv3 --kernel-trace --stats -d "$OUT/p4" -o p --output-format csv -- python3 "$ROOT/tools/bench_wino.py" pmc > /dev/null 2>&1
+cp "$(find "$OUT/p4" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_wino_dc_conv1.csv"; rm -rf "$OUT/p4"
+python3 "$ROOT/tools/bench_wino.py" layers > "$OUT/microbench_wino_layers.txt" 2>&1
 python3 "$ROOT/tools/bench_warpcorr.py" > "$OUT/microbench_warpcorr.txt" 2>&1
 PWC_BENCH_LEVELS=2 rocprofv3 --kernel-trace --stats -d "$OUT/p2" -o p --output-format csv -- python3 "$ROOT/tools/bench_warpcorr.py" > /dev/null 2>&1
 cp "$(find "$OUT/p2" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_warpcorr.csv"; rm -rf "$OUT/p2"
@@ -49,11 +52,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_mfma_kernel $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_wino.py" pmc > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino_kernel $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   PWC_BENCH_LEVELS=2 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_warpcorr.py" > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernel<true>" $c >> "$OUT/pmc_summary.txt"
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernel<false>" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
 done
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+  rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_wino.py" pmc > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino_kernel $c >> "$OUT/pmc_summary.txt"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_mfma_kernel $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
 done

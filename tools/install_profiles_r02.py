@@ -20,10 +20,10 @@ COPIES = {
     "forward_timeline_b16.txt": "r02_forward_timeline_b16.txt", "f16_forward_timeline_b16.txt": "r02_f16_forward_timeline_b16.txt",
     "kernel_stats_bench_b16.csv": "r02_kernel_stats_bench_b16.csv", "f16_kernel_stats_bench_b16.csv": "r02_f16_kernel_stats_bench_b16.csv",
     "kernel_stats_dc_conv1.csv": "r02_kernel_stats_dc_conv1_alone.csv", "f16_kernel_stats_dc_conv1.csv": "r02_f16_kernel_stats_dc_conv1_alone.csv",
-    "kernel_stats_warpcorr.csv": "r02_kernel_stats_warpcorr_alone.csv", "pmc_summary.txt": "r02_pmc_summary.txt",
+    "kernel_stats_warpcorr.csv": "r02_kernel_stats_warpcorr_alone.csv", "kernel_stats_wino_dc_conv1.csv": "r02_kernel_stats_wino_dc_conv1_alone.csv", "pmc_summary.txt": "r02_pmc_summary.txt",
 }
 FILTERED = {"microbench_warpcorr.txt": ("r02_microbench_warpcorr.txt", ("level",)), "microbench_bwd.txt": ("r02_microbench_bwd.txt", ("corr", "warp")),
-            "microbench_pyr1.txt": ("r02_microbench_pyr1.txt", ("fused", "layers")), "microbench_corr.txt": ("r02_microbench_corr.txt", ("corr", "warp", "copy")),
+            "microbench_pyr1.txt": ("r02_microbench_pyr1.txt", ("fused", "layers")), "microbench_wino_layers.txt": ("r02_microbench_wino_layers.txt", ("conv", "dc_")), "microbench_corr.txt": ("r02_microbench_corr.txt", ("corr", "warp", "copy")),
             "f16_microbench_conv.txt": ("r02_f16_microbench_conv.txt", ("dc_", "conv"))}
 
 
@@ -67,7 +67,10 @@ def main():
                                               "round 1 ASSUMED the same for dword LDS-DMA, this is the measurement"}}
     f4 = cal[4] or 2.0
     f16 = cal[16] or 2.0
-    rows = (("conv3x3_mfma_dc_conv1_b16", "conv3x3_mfma_kernel", f4, "kernel_stats_dc_conv1.csv", "conv3x3_mfma_kernel", 1274277888,
+    rows = (("conv3x3_wino_dc_conv1_b16", "conv3x3_wino_kernel", f4, "kernel_stats_wino_dc_conv1.csv", "conv3x3_wino_kernel", 1276313600,
+             "fp32 dc_conv1 565->128 @112x256 B=16 by Winograd F(2x2,3x3): input by dword LDS-DMA (x2 correction), G g Gt filters "
+             "(4.7 MB, re-read per workgroup from L2) by 16-byte LDS-DMA; algorithmic = input + filters once + output"),
+            ("conv3x3_mfma_dc_conv1_b16", "conv3x3_mfma_kernel", f4, "kernel_stats_dc_conv1.csv", "conv3x3_mfma_kernel", 1274277888,
              "fp32 dc_conv1 565->128 @112x256 B=16 (dword LDS-DMA input staging, 16-byte filter staging)"),
             ("conv3x3_f16_dc_conv1_b16", "conv3x3_f16", f16, "f16_kernel_stats_dc_conv1.csv", "conv3x3_f16", 647249920,
              "fp16 dc_conv1 (8-wave kernel, two 64-cout groups): every fetch is a 16-byte LDS-DMA piece"),
