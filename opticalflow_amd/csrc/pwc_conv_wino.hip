@@ -358,6 +358,280 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
     }
 }
 
+// ---- the same algorithm with EIGHT waves (two per SIMD) --------------------------------------------------------------
+// With one wave per SIMD every instruction that is not an MFMA competes with the MFMAs for the wave's single in-order issue
+// slot: the four-wave kernel above keeps the matrix pipe 75 % (128-cout layers) to 55 % (32-cout layers) busy.  Here the 16
+// positions of a (cout block, tile group) pair are split between two waves (8 positions = 128 accumulator registers each), so
+// the workgroup has 8 waves, two per SIMD, and one wave's LDS-DMA / transform / operand reads issue while the other wave's
+// MFMAs run.  The price is an exchange at the end: At M A needs all four rows of M, each wave of a pair holds two; the
+// waves swap one row each through LDS (M1 one way, M2 the other) and each finishes ONE of the two output rows.
+constexpr int kThreads8 = 512;
+#ifndef PWC_WINO_EXP
+#define PWC_WINO_EXP 0        // timing experiments (results invalid): 1 no U DMA, 2 no raw DMA, 4 no transform, 8 no barrier/wait
+#endif
+
+template <int MT>
+__global__ void __launch_bounds__(kThreads8, 1)
+conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+                     float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil) {
+    using G = Geo<MT>;
+    constexpr int TG = G::kTG;
+    constexpr int RS = (G::kRawElems + kThreads8 - 1) / kThreads8;        // dword LDS-DMAs per thread and chunk
+    constexpr int US = G::kUFloats / 4 / kThreads8;                        // 16-byte LDS-DMAs per thread and chunk (= MT)
+    static_assert(RS * kThreads8 <= G::kRawRegion && US >= 1, "geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *raw = smem;                                  // [3][kRawRegion]
+    float *ubuf = smem + 3 * G::kRawRegion;             // [3][kUFloats]
+    float *vbuf = ubuf + 3 * G::kUFloats;               // [2][kVFloats]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int col = lane & 31;
+    const int kh = lane >> 5;
+
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    const int sub = bid % (dil * dil);                  // pixel lattice of a dilated layer (see conv3x3_wino_kernel)
+    bid /= dil * dil;
+    const int ry = sub / dil, rx = sub % dil;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int g = blockIdx.y;
+    const int ox0 = tx * kTW;
+    const int oy0 = ty * (kGH * TG);
+    const int plane = H * W;
+
+    unsigned raw_off[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) {
+        const int i = j * kThreads8 + tid;
+        const int c = i / G::kRawPlane;
+        const int rem = i % G::kRawPlane;
+        const int iy = ry + dil * (oy0 - 1 + rem / kRawW);
+        const int ix = rx + dil * (ox0 - 1 + rem % kRawW);
+        const bool ok = (i < G::kRawElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+        raw_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+    }
+    unsigned u_off[US];
+#pragma unroll
+    for (int j = 0; j < US; ++j) {
+        const int p = j * kThreads8 + tid;
+        const int row = p / (16 * MT);
+        const int q = p % (16 * MT);
+        u_off[j] = (unsigned)(row * CoutP * 2 + q * 4) * 4u;
+    }
+
+    const float *xb = x + (int64_t)b * bsx;
+    const int nchunks = (Cin + kCK - 1) / kCK;
+    const int64_t uchunk = (int64_t)64 * CoutP;
+    const float *ug = up + g * G::kCoutT * 2;
+    const int ubytes = (int)(uchunk - g * G::kCoutT * 2) * 4;
+    const unsigned lds_raw = pwc::lds_addr(raw) + wave * 256;
+    const unsigned lds_u = pwc::lds_addr(ubuf) + wave * 1024;
+
+    pwc::v4i32 rs_raw, rs_u;
+    unsigned base_raw = 0, base_u = 0;
+    auto setup_raw = [&](int chunk, int slot) {
+        const int c0 = chunk * kCK;
+        rs_raw = pwc::make_rsrc(xb + (int64_t)c0 * plane, min(kCK, Cin - c0) * plane * 4);
+        base_raw = __builtin_amdgcn_readfirstlane(lds_raw + slot * G::kRawRegion * 4);
+    };
+    auto setup_u = [&](int chunk, int slot) {
+        rs_u = pwc::make_rsrc(ug + (int64_t)chunk * uchunk, ubytes);
+        base_u = __builtin_amdgcn_readfirstlane(lds_u + slot * G::kUFloats * 4);
+    };
+    // transform: a thread makes ONE row i of V = Bt d B per unit (4 of the 16 positions) for one (channel, tile):
+    //   Bt row 0 = d0 - d2, 1 = d1 + d2, 2 = d2 - d1, 3 = d1 - d3  ->  w = ra + sgn * rb with (ra, rb) = (0,2) (1,2) (2,1) (1,3)
+    int src_a[TG], src_b[TG], dst[TG];
+    float sgn[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        const int u = t * kThreads8 + tid;
+        const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, i = u / (128 * TG);
+        const int tgi = n >> 5, tile = n & 31;
+        const int ra = (i == 0) ? 0 : (i == 2) ? 2 : 1, rb = (i == 2) ? 1 : (i == 3) ? 3 : 2;
+        const int base = c * G::kRawPlane + (kGH * tgi + 2 * (tile >> 4)) * kRawW + 2 * (tile & 15);
+        src_a[t] = base + ra * kRawW;
+        src_b[t] = base + rb * kRawW;
+        sgn[t] = (i == 1) ? 1.f : -1.f;
+        dst[t] = ((tgi * 16 + i * 4) * 2 + (c >> 1)) * 64 + tile * 2 + (c & 1);
+    }
+    f32x2 da[TG][2], db[TG][2];
+    float vo4[TG][4];
+    auto unit_load = [&](int t, int rslot) {
+        const float *p = raw + rslot * G::kRawRegion;
+        da[t][0] = *reinterpret_cast<const f32x2 *>(p + src_a[t]);
+        da[t][1] = *reinterpret_cast<const f32x2 *>(p + src_a[t] + 2);
+        db[t][0] = *reinterpret_cast<const f32x2 *>(p + src_b[t]);
+        db[t][1] = *reinterpret_cast<const f32x2 *>(p + src_b[t] + 2);
+    };
+    auto unit_math = [&](int t) {
+        const float w0 = __builtin_fmaf(sgn[t], db[t][0][0], da[t][0][0]), w1 = __builtin_fmaf(sgn[t], db[t][0][1], da[t][0][1]);
+        const float w2 = __builtin_fmaf(sgn[t], db[t][1][0], da[t][1][0]), w3 = __builtin_fmaf(sgn[t], db[t][1][1], da[t][1][1]);
+        vo4[t][0] = w0 - w2;
+        vo4[t][1] = w1 + w2;
+        vo4[t][2] = w2 - w1;
+        vo4[t][3] = w1 - w3;
+    };
+    auto unit_store = [&](int t, int vslot) {
+        float *vo = vbuf + vslot * G::kVFloats + dst[t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vo[j * 128] = vo4[t][j];
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[p][j] = 0.f;
+
+    const int pw = wave >> 1, ph = wave & 1;            // pair (cout block, tile group); position half
+    const int blk = pw % MT, tgw = pw / MT;
+    const int ua_off = (ph * 8 * 2 + kh) * G::kCoutT * 2 + (blk * 32 + col) * 2;          // position p0 = 8*ph
+    const int vb_off = tgw * G::kVGroup + ph * 8 * 128 + (kh * 32 + col) * 2;
+    f32x2 a2[2][4], b2[2][4];                           // operand sets: local positions 0..3 -> set 0, 4..7 -> set 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a2[1][i] = b2[1][i] = (f32x2){0.f, 0.f};
+
+    // (Giving waves 4..7 -- the second wave of each SIMD -- a schedule with the LDS-DMA and the transform in the other half of
+    // the iteration was measured: no gain, 2.23 vs 2.21 ms on dc_conv1.  The two waves of a SIMD share its issue bandwidth.)
+    auto iteration = [&](int k, int r3, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int r1 = (r3 == 2) ? 0 : r3 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
+        const bool do_raw = (FULL || (k + 3 < nchunks)) && !(PWC_WINO_EXP & 2), do_u = (FULL || (k + 2 < nchunks)) && !(PWC_WINO_EXP & 1),
+                   do_tr = (FULL || (k + 1 < nchunks)) && !(PWC_WINO_EXP & 4);
+        if (!(PWC_WINO_EXP & 8)) {
+            if (FULL || k + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RS + US) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        const float *ua = ubuf + r3 * G::kUFloats + ua_off;
+        const float *vb = vbuf + (k & 1) * G::kVFloats + vb_off;
+        constexpr int kDma0 = 3, kSetup = 2, kTr0 = 2;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int q = (s >> 3) - 1, i = s & 7;              // q = -1: local positions 4..7 of the previous chunk (set 1)
+            const int pq = (q < 0) ? 1 : 0;
+            acc[4 * pq + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[pq][i & 3][i >> 2], b2[pq][i & 3][i >> 2], acc[4 * pq + (i & 3)], 0, 0, 0);
+            if (s < 4) {                                        // operands of local positions 0..3 of this chunk
+                a2[0][s] = *reinterpret_cast<const f32x2 *>(ua + s * (2 * G::kCoutT * 2));
+                b2[0][s] = *reinterpret_cast<const f32x2 *>(vb + s * 128);
+            }
+            if (s >= 8 && s < 12) {                             // ... and of 4..7 (consumed behind the next barrier)
+                a2[1][s - 8] = *reinterpret_cast<const f32x2 *>(ua + (s - 4) * (2 * G::kCoutT * 2));
+                b2[1][s - 8] = *reinterpret_cast<const f32x2 *>(vb + (s - 4) * 128);
+            }
+            if (s == kSetup) {
+                if (do_raw) setup_raw(k + 3, r3);
+                if (do_u) setup_u(k + 2, r2);
+            }
+            if (s >= kDma0 && s < kDma0 + RS) {
+                if (do_raw) pwc::dma_b32(rs_raw, base_raw + (s - kDma0) * kThreads8 * 4, raw_off[s - kDma0]);
+            } else if (s >= kDma0 + RS && s < kDma0 + RS + US) {
+                if (do_u) pwc::dma_b128(rs_u, base_u + (s - kDma0 - RS) * kThreads8 * 16, u_off[s - kDma0 - RS]);
+            }
+            if (do_tr) {
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    const int phs = s - kTr0 - 3 * t;
+                    if (phs == 0) unit_load(t, r1);
+                    else if (phs == 2) unit_math(t);
+                    else if (phs == 3) unit_store(t, (k + 1) & 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // prologue: raw(0) -> V(0); then the two groups the loop expects in flight: {raw(1), U(0)} and {raw(2), U(1)}
+    setup_raw(0, 0);
+#pragma unroll
+    for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads8 * 4, raw_off[j]);
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+        if (gq + 1 < nchunks) {
+            setup_raw(gq + 1, gq + 1);
+#pragma unroll
+            for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads8 * 4, raw_off[j]);
+        }
+        if (gq < nchunks) {
+            setup_u(gq, gq);
+#pragma unroll
+            for (int j = 0; j < US; ++j) pwc::dma_b128(rs_u, base_u + j * kThreads8 * 16, u_off[j]);
+        }
+    }
+    if (nchunks >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (RS + US)) : "memory");     // raw(0) only
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        unit_load(t, 0);
+        unit_math(t);
+        unit_store(t, 0);
+    }
+    int r3 = 0;
+    int k = 0;
+    for (; k + 3 < nchunks; ++k) {
+        iteration(k, r3, std::true_type{});
+        r3 = (r3 == 2) ? 0 : r3 + 1;
+    }
+    for (; k < nchunks; ++k) {
+        iteration(k, r3, std::false_type{});
+        r3 = (r3 == 2) ? 0 : r3 + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)               // local positions 4..7 of the last chunk
+        acc[4 + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][i & 3][i >> 2], b2[1][i & 3][i >> 2], acc[4 + (i & 3)], 0, 0, 0);
+
+    // ---- output transform: wave ph=0 holds M rows 0,1 (acc[0..3], acc[4..7]), ph=1 rows 2,3.  Row 0 of Y needs
+    // M0 + M1 + M2, row 1 needs M1 - M2 - M3: ph=0 sends M1, ph=1 sends M2, 8 cout rows (32 floats per lane) at a time.
+    const int oy = ry + dil * (oy0 + kGH * tgw + 2 * (col >> 4) + ph);      // the output row this wave finishes
+    const int ox = rx + dil * (ox0 + 2 * (col & 15));
+    const bool inside = (oy < H) && (ox < W);
+    const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
+    float bvs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bvs[j] = bias[min(g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
+    float *xsend = smem + ((pw * 2 + ph) * 32) * 64 + lane;               // [pair][sender][32][64 lanes]
+    const float *xrecv = smem + ((pw * 2 + (ph ^ 1)) * 32) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        __syncthreads();                      // the rings (round 0) / the previous round's rows are no longer read
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xsend[(jj * 4 + c) * 64] = ph ? acc[c][8 * r + jj] : acc[4 + c][8 * r + jj];
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = 8 * r + jj;
+            const int co = g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            float tt[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float other = xrecv[(jj * 4 + c) * 64];
+                // ph 0: M0 + M1 + M2(other);   ph 1: M1(other) - M2 - M3
+                tt[c] = ph ? (other - acc[c][j] - acc[4 + c][j]) : (acc[c][j] + acc[4 + c][j] + other);
+            }
+            float ya = tt[0] + tt[1] + tt[2] + bvs[j], yb = tt[1] - tt[2] - tt[3] + bvs[j];
+            if (do_leaky) { ya = leaky(ya, slope); yb = leaky(yb, slope); }
+            if (inside && co < Cout) {
+                float *o = y + obase + (int64_t)co * plane;
+                if (vec2) {
+                    *reinterpret_cast<f32x2 *>(o) = (f32x2){ya, yb};
+                } else {
+                    o[0] = ya;
+                    if (ox + dil < W) o[dil] = yb;
+                }
+            }
+        }
+    }
+}
+
 inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
 
 template <int MT>
@@ -374,6 +648,17 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y * dil * dil;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: grid too large");
     const int vec2 = dil == 1 && (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
+    static const int waves = [] { const char *e = getenv("PWC_WINO_WAVES"); return (e && *e) ? atoi(e) : 8; }();
+    if (waves == 8) {
+        static pwc::LdsAttrOnce once8;
+        if (const int rc = pwc::ensure_lds_attr(once8, reinterpret_cast<const void *>(&conv3x3_wino8_kernel<MT>), G::kSmemBytes,
+                                                "conv3x3_wino8_kernel"))
+            return rc;
+        hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)(CoutP / G::kCoutT)), dim3(kThreads8), G::kSmemBytes, st,
+                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil);
+        pwc::note_kernel("conv3x3_wino8_kernel", MT, G::kTG, 1, dil, 1, 0);
+        return pwc::check_launch("conv3x3_wino8_kernel");
+    }
     hipLaunchKernelGGL(conv3x3_wino_kernel<MT>, dim3((unsigned)nblk, (unsigned)(CoutP / G::kCoutT)), dim3(kThreads), G::kSmemBytes, st,
                        x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil);
     pwc::note_kernel("conv3x3_wino_kernel", MT, G::kTG, 1, dil, 1, 0);
