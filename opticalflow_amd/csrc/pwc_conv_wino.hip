@@ -88,7 +88,7 @@ template <int MT>
 __global__ void __launch_bounds__(kThreads, 1)
 conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                     float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                    int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil) {
+                    int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil, int co0) {
     using G = Geo<MT>;
     constexpr int TG = G::kTG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -115,7 +115,7 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int g = blockIdx.y;
+    const int cb = co0 + (int)blockIdx.y * G::kCoutT;         // first cout of this workgroup
     const int ox0 = tx * kTW;
     const int oy0 = ty * (kGH * TG);
     const int plane = H * W;
@@ -144,8 +144,8 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
     const float *xb = x + (int64_t)b * bsx;
     const int nchunks = (Cin + kCK - 1) / kCK;
     const int64_t uchunk = (int64_t)64 * CoutP;              // floats per chunk of the packed image
-    const float *ug = up + g * G::kCoutT * 2;
-    const int ubytes = (int)(uchunk - g * G::kCoutT * 2) * 4;
+    const float *ug = up + cb * 2;
+    const int ubytes = (int)(uchunk - cb * 2) * 4;
     const unsigned lds_raw = pwc::lds_addr(raw) + wave * 256;         // + slot*kRawRegion*4 + j*1024
     const unsigned lds_u = pwc::lds_addr(ubuf) + wave * 1024;         // + slot*kUFloats*4 + j*4096
 
@@ -328,10 +328,10 @@ conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, c
     const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
     float bvs[16];                            // one batch of loads, one wait (16 dependent round trips otherwise)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bvs[j] = bias[min(g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
+    for (int j = 0; j < 16; ++j) bvs[j] = bias[min(cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int co = g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+        const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
         if (co >= Cout) continue;
         float t0[4], t1[4];
 #pragma unroll
@@ -374,7 +374,7 @@ template <int MT>
 __global__ void __launch_bounds__(kThreads8, 1)
 conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil) {
+                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil, int co0) {
     using G = Geo<MT>;
     constexpr int TG = G::kTG;
     constexpr int RS = (G::kRawElems + kThreads8 - 1) / kThreads8;        // dword LDS-DMAs per thread and chunk
@@ -400,7 +400,7 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int g = blockIdx.y;
+    const int cb = co0 + (int)blockIdx.y * G::kCoutT;         // first cout of this workgroup
     const int ox0 = tx * kTW;
     const int oy0 = ty * (kGH * TG);
     const int plane = H * W;
@@ -428,8 +428,8 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     const float *xb = x + (int64_t)b * bsx;
     const int nchunks = (Cin + kCK - 1) / kCK;
     const int64_t uchunk = (int64_t)64 * CoutP;
-    const float *ug = up + g * G::kCoutT * 2;
-    const int ubytes = (int)(uchunk - g * G::kCoutT * 2) * 4;
+    const float *ug = up + cb * 2;
+    const int ubytes = (int)(uchunk - cb * 2) * 4;
     const unsigned lds_raw = pwc::lds_addr(raw) + wave * 256;
     const unsigned lds_u = pwc::lds_addr(ubuf) + wave * 1024;
 
@@ -595,7 +595,7 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
     float bvs[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bvs[j] = bias[min(g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
+    for (int j = 0; j < 16; ++j) bvs[j] = bias[min(cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
     float *xsend = smem + ((pw * 2 + ph) * 32) * 64 + lane;               // [pair][sender][32][64 lanes]
     const float *xrecv = smem + ((pw * 2 + (ph ^ 1)) * 32) * 64 + lane;
 #pragma unroll
@@ -609,7 +609,7 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = 8 * r + jj;
-            const int co = g * G::kCoutT + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
             float tt[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -636,7 +636,7 @@ inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
 
 template <int MT>
 int launch_wino(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int dil,
-                int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st) {
+                int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups) {
     using G = Geo<MT>;
     static pwc::LdsAttrOnce once;
     if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino_kernel<MT>), G::kSmemBytes,
@@ -654,13 +654,13 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
         if (const int rc = pwc::ensure_lds_attr(once8, reinterpret_cast<const void *>(&conv3x3_wino8_kernel<MT>), G::kSmemBytes,
                                                 "conv3x3_wino8_kernel"))
             return rc;
-        hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)(CoutP / G::kCoutT)), dim3(kThreads8), G::kSmemBytes, st,
-                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil);
+        hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups), dim3(kThreads8), G::kSmemBytes, st,
+                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0);
         pwc::note_kernel("conv3x3_wino8_kernel", MT, G::kTG, 1, dil, 1, 0);
         return pwc::check_launch("conv3x3_wino8_kernel");
     }
-    hipLaunchKernelGGL(conv3x3_wino_kernel<MT>, dim3((unsigned)nblk, (unsigned)(CoutP / G::kCoutT)), dim3(kThreads), G::kSmemBytes, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil);
+    hipLaunchKernelGGL(conv3x3_wino_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups), dim3(kThreads), G::kSmemBytes, st,
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0);
     pwc::note_kernel("conv3x3_wino_kernel", MT, G::kTG, 1, dil, 1, 0);
     return pwc::check_launch("conv3x3_wino_kernel");
 }
@@ -713,7 +713,35 @@ extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *b
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
     const int CoutP = cout_padded(Cout);
-    if (CoutP % 128 == 0) return launch_wino<4>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st);
-    if (CoutP % 64 == 0) return launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st);
-    return launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st);
+    // cout blocks of 32: as many 128-wide workgroups as fit, then a 64-wide and a 32-wide launch for the rest (96 = 64 + 32: the
+    // wider the cout tile, the fewer tile groups share a workgroup and the smaller the transform's share of the issue slots)
+    static const int force_mt = [] { const char *e = getenv("PWC_WINO_MT"); return (e && *e) ? atoi(e) : 0; }();    // experiments
+    const int nblk32 = CoutP / 32;
+    int co0 = 0;
+    if (force_mt == 1 || force_mt == 2) {
+        if (force_mt == 2 && nblk32 % 2 == 0)
+            return launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32 / 2);
+        return launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32);
+    }
+    // ... when the narrowest launch still covers the chip; otherwise one launch of the widest tile that divides CoutP
+    const int Hs = (H + dilation - 1) / dilation, Ws = (W + dilation - 1) / dilation;
+    const int64_t wg32 = (int64_t)B * ((Ws + kTW - 1) / kTW) * ((Hs + 4 * kGH - 1) / (4 * kGH)) * dilation * dilation;   // 32-cout launch
+    const int64_t wg64 = (int64_t)B * ((Ws + kTW - 1) / kTW) * ((Hs + 2 * kGH - 1) / (2 * kGH)) * dilation * dilation;
+    const bool ragged = (nblk32 % 4) != 0 && nblk32 != 1 && nblk32 != 2;
+    if (ragged && ((nblk32 % 2) ? wg32 : wg64) < 256) {
+        if (nblk32 % 2 == 0)
+            return launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32 / 2);
+        return launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32);
+    }
+    if (nblk32 >= 4) {
+        if (const int rc = launch_wino<4>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32 / 4)) return rc;
+        co0 = nblk32 / 4 * 128;
+    }
+    if ((nblk32 % 4) >= 2) {
+        if (const int rc = launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, co0, 1)) return rc;
+        co0 += 64;
+    }
+    if (nblk32 % 2)
+        return launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, co0, 1);
+    return PWC_OK;
 }
