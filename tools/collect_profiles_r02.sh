@@ -53,14 +53,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_wino.py" pmc > /dev/null 2>&1
-  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino_kernel $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   PWC_BENCH_LEVELS=2 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_warpcorr.py" > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernel<true>" $c >> "$OUT/pmc_summary.txt"
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" "corr81_dma_kernel<false>" $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
 done
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_wino.py" pmc > /dev/null 2>&1
-  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino_kernel $c >> "$OUT/pmc_summary.txt"
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino $c >> "$OUT/pmc_summary.txt"
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_mfma_kernel $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
   PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"

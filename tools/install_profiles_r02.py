@@ -67,7 +67,7 @@ def main():
                                               "round 1 ASSUMED the same for dword LDS-DMA, this is the measurement"}}
     f4 = cal[4] or 2.0
     f16 = cal[16] or 2.0
-    rows = (("conv3x3_wino_dc_conv1_b16", "conv3x3_wino_kernel", f4, "kernel_stats_wino_dc_conv1.csv", "conv3x3_wino_kernel", 1276313600,
+    rows = (("conv3x3_wino_dc_conv1_b16", "conv3x3_wino", f4, "kernel_stats_wino_dc_conv1.csv", "conv3x3_wino", 1276313600,
              "fp32 dc_conv1 565->128 @112x256 B=16 by Winograd F(2x2,3x3): input by dword LDS-DMA (x2 correction), G g Gt filters "
              "(4.7 MB, re-read per workgroup from L2) by 16-byte LDS-DMA; algorithmic = input + filters once + output"),
             ("conv3x3_mfma_dc_conv1_b16", "conv3x3_mfma_kernel", f4, "kernel_stats_dc_conv1.csv", "conv3x3_mfma_kernel", 1274277888,

@@ -24,9 +24,9 @@ def short(n):
     m = (re.search(r"conv3x3_f16w8_kernel<(\d+), (\d+)", n) or re.search(r"conv3x3_f16w8_kernelILi(\d+)ELi(\d+)E", n))
     if m:
         return "f16w8<MT%s,D%s>" % m.groups()
-    m = re.search(r"conv3x3_wino_kernel<(\d+)>", n) or re.search(r"conv3x3_wino_kernelILi(\d+)E", n)
+    m = re.search(r"conv3x3_wino(8?)_kernel<(\d+)>", n) or re.search(r"conv3x3_wino(8?)_kernelILi(\d+)E", n)
     if m:
-        return "wino<MT%s>" % m.group(1)
+        return "wino%s<MT%s>" % m.groups()
     m = re.search(r"stream3x3_kernel<(\d+), (\d+), (\d+)>", n)
     if m:
         return "stream3x3<mode%s,TH%s,KS%s>" % m.groups()
