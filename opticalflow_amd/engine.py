@@ -6,8 +6,9 @@ What the reference does per forward (models/PWCNet.py:180-273) and what the plan
     1024x448 pair): the plan allocates ONE arena ``[B, Ctot, H, W]`` per level whose channel order
     is the final concatenation order
         [conv_4 | conv_3 | conv_2 | conv_1 | conv_0 | corr | c1 | up_flow | up_feat]
-    and every producer (dense convs, correlation, last pyramid conv, the two deconvs) writes its
-    channel slice in place; a consumer reads a channel *suffix* -- only the batch stride differs
+    and every producer (dense convs, correlation, the two deconvs) writes its channel slice in
+    place (the first image's pyramid features are COPIED into their slot, 46 us per forward at
+    batch 16: the pyramid runs both images as one 2B batch with one output stride); a consumer reads a channel *suffix* -- only the batch stride differs
     from a dense tensor, which the C ABI takes as an argument.
   * warp: one fused kernel instead of mesh + 2x grid_sample + mask ops (PWCNet.py:141-177), with the
     per-level flow scale (PWCNet.py:212,226,240,256) folded in.
