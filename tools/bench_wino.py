@@ -45,10 +45,10 @@ if mode == "pmc":          # one layer, few launches, for the counter passes of 
     b = torch.zeros(cout, device=dev)
     up, wp = ops.pack_conv3x3_wino(w), ops.pack_conv3x3(w)
     y = torch.empty(B, cout, H, W, device=dev)
-    for _ in range(16):        # back to back, as in the forward's steady state (the profiler's average is over these)
-        ops.conv3x3_wino(x, up, b, cout, out=y)
-    for _ in range(4):
+    for _ in range(40):        # the direct kernel first: ~160 ms that bring the clocks up (a different kernel name in the trace)
         ops.conv3x3(x, wp, b, cout, out=y)
+    for _ in range(30):        # back to back, as in the forward's steady state: the profiler's average is over these
+        ops.conv3x3_wino(x, up, b, cout, out=y)
     torch.cuda.synchronize()
 
 if mode == "layers":       # every stride-1 / dilation-1 3x3 layer of the forward at batch 16 (pyramid: 32 images)
