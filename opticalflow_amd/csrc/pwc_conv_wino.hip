@@ -27,6 +27,7 @@ namespace {
 using pwc::leaky;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kCK = 4;               // input channels per chunk
@@ -606,10 +607,10 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
 #pragma unroll
             for (int c = 0; c < 4; ++c) xsend[(jj * 4 + c) * 64] = ph ? acc[c][8 * r + jj] : acc[4 + c][8 * r + jj];
         __syncthreads();
+        float ya[8], yb[8];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int j = 8 * r + jj;
-            const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
             float tt[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -617,15 +618,37 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
                 // ph 0: M0 + M1 + M2(other);   ph 1: M1(other) - M2 - M3
                 tt[c] = ph ? (other - acc[c][j] - acc[4 + c][j]) : (acc[c][j] + acc[4 + c][j] + other);
             }
-            float ya = tt[0] + tt[1] + tt[2] + bvs[j], yb = tt[1] - tt[2] - tt[3] + bvs[j];
-            if (do_leaky) { ya = leaky(ya, slope); yb = leaky(yb, slope); }
-            if (inside && co < Cout) {
-                float *o = y + obase + (int64_t)co * plane;
-                if (vec2) {
-                    *reinterpret_cast<f32x2 *>(o) = (f32x2){ya, yb};
-                } else {
-                    o[0] = ya;
-                    if (ox + dil < W) o[dil] = yb;
+            ya[jj] = tt[0] + tt[1] + tt[2] + bvs[j];
+            yb[jj] = tt[1] - tt[2] - tt[3] + bvs[j];
+            if (do_leaky) { ya[jj] = leaky(ya[jj], slope); yb[jj] = leaky(yb[jj], slope); }
+        }
+        if (vec2 == 2) {
+            // 16-byte stores: the lanes of two neighbouring tiles (2 + 2 pixels of one row) swap halves -- the even lane ends up
+            // with the four pixels of cout j, the odd lane with those of cout j + 1 -- so a lane issues 8 stores instead of 16
+            // (the store tail of a workgroup is issue-bound: MI355X guide, "epilogue store tail")
+            const int odd = lane & 1;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj += 2) {
+                const int j = 8 * r + jj;
+                const float s0 = odd ? ya[jj] : ya[jj + 1], s1 = odd ? yb[jj] : yb[jj + 1];
+                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh + odd;
+                const f32x4 v = odd ? (f32x4){r0, r1, ya[jj + 1], yb[jj + 1]} : (f32x4){ya[jj], yb[jj], r0, r1};
+                if (inside && co < Cout) *reinterpret_cast<f32x4 *>(y + obase - 2 * odd + (int64_t)co * plane) = v;
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = 8 * r + jj;
+                const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+                if (inside && co < Cout) {
+                    float *o = y + obase + (int64_t)co * plane;
+                    if (vec2) {
+                        *reinterpret_cast<f32x2 *>(o) = (f32x2){ya[jj], yb[jj]};
+                    } else {
+                        o[0] = ya[jj];
+                        if (ox + dil < W) o[dil] = yb[jj];
+                    }
                 }
             }
         }
@@ -647,7 +670,8 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
     const int tiles_x = (Ws + kTW - 1) / kTW, tiles_y = (Hs + kGH * G::kTG - 1) / (kGH * G::kTG);
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y * dil * dil;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: grid too large");
-    const int vec2 = dil == 1 && (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
+    int vec2 = dil == 1 && (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
+    if (vec2 && (W % 4 == 0) && (bsy % 4 == 0) && !(reinterpret_cast<uintptr_t>(y) & 15u)) vec2 = 2;      // 16-byte stores (8-wave kernel)
     static const int waves = [] { const char *e = getenv("PWC_WINO_WAVES"); return (e && *e) ? atoi(e) : 8; }();
     if (waves == 8) {
         static pwc::LdsAttrOnce once8;

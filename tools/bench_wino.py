@@ -94,6 +94,30 @@ if mode == "layers":       # every stride-1 / dilation-1 3x3 layer of the forwar
         print("%-12s B%-2d %3d->%3d @%3dx%-3d: wino %7.1f us   direct %7.1f us   x%.2f   preferred=%d   max diff %.1e" %
               (name, B, cin, cout, H, W, tw * 1e3, td * 1e3, td / tw, ops.conv3x3_wino_preferred(B, cin, H, W, cout, D), (y - y0).abs().max().item()), flush=True)
 
+if mode == "kscan":        # time against the number of 4-channel chunks at fixed geometry: slope = per-chunk time, intercept = fixed cost per launch
+    B, H, W = 16, 112, 256
+    for cout in (128, 64, 32):
+        pts = []
+        for cin in (16, 32, 64, 128, 256, 512):
+            x = torch.randn(B, cin, H, W, device=dev)
+            w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (cin * 9)) ** 0.5
+            b = torch.zeros(cout, device=dev)
+            up = ops.pack_conv3x3_wino(w)
+            y = torch.empty(B, cout, H, W, device=dev)
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                ops.conv3x3_wino(x, up, b, cout, out=y)
+            torch.cuda.synchronize()
+            s_.record()
+            for _ in range(20):
+                ops.conv3x3_wino(x, up, b, cout, out=y)
+            e_.record()
+            e_.synchronize()
+            pts.append((cin // 4, s_.elapsed_time(e_) / 20 * 1e3))
+        (k0, t0), (k1, t1) = pts[2], pts[-1]
+        slope = (t1 - t0) / (k1 - k0)
+        print("cout %3d: " % cout + "  ".join("%d:%.0fus" % p_ for p_ in pts) + "   slope %.2f us/chunk, intercept %.0f us per launch" % (slope, t0 - slope * k0), flush=True)
+
 if mode in ("time", "all"):
     B, H, W = 16, 112, 256
 
