@@ -742,7 +742,7 @@ def test_forward_winograd_route_matches_direct_route(gpu_device, monkeypatch):
     """The whole fp32 forward with the Winograd layers against the same forward on the direct kernels (PWC_CONV_WINO=0)."""
     from opticalflow_amd import PWCDCNet
     from opticalflow_amd.weights import synthetic_state_dict
-    x = torch.rand(2, 6, 256, 512, generator=torch.Generator().manual_seed(11)).to(gpu_device)
+    x = torch.rand(4, 6, 256, 512, generator=torch.Generator().manual_seed(11)).to(gpu_device)     # big enough for the rule to say yes
     flows = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("PWC_CONV_WINO", flag)
@@ -750,6 +750,9 @@ def test_forward_winograd_route_matches_direct_route(gpu_device, monkeypatch):
         net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
         net = net.to(gpu_device).eval()
         flows[flag] = net(x).clone()
-        assert bool(net._plan_for(x).wino) == (flag == "1")
+        plan = net._plan_for(x)
+        assert bool(plan.wino) == (flag == "1")
+        # the plan counts the multiplications of its 3x3 layers: fewer than a direct convolution only on the Winograd route
+        assert (plan.conv_macs["executed"] < plan.conv_macs["direct"]) == (flag == "1")
     epe = (flows["1"] - flows["0"]).pow(2).sum(1).sqrt().mean().item()
     assert epe < 2e-5, epe
