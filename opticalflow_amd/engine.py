@@ -288,6 +288,9 @@ class PwcPlan:
             tot += sum(t.numel() * t.element_size() for t in group.values())
         tot += sum(t.numel() * t.element_size() for t in self.ctx + [self.flow_out])
         tot += sum(t.numel() * t.element_size() for t in self.packed.values())
+        tot += sum(t.numel() * t.element_size() for t in self.wino_packed.values())
+        if self.workspace is not None:
+            tot += self.workspace.numel() * self.workspace.element_size()
         return tot
 
 
