@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 6
+#define PWC_ABI_VERSION 7
 
 /* element types */
 #define PWC_F32 0
@@ -156,7 +156,10 @@ int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout, int dilat
 int pwc_conv3x3_wino_pack(const void *w, void *up, int Cin, int Cout, void *stream);
 int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *y,
                          int B, int Cin, int H, int W, int Cout, int dilation, unsigned flags, float leaky_slope,
-                         int64_t x_bstride, int64_t y_bstride, void *stream);
+                         int64_t x_bstride, int64_t y_bstride, void *workspace, int64_t workspace_bytes, void *stream);
+/* workspace (device, may be NULL): scratch for the split-K form taken by launches that would leave most CUs idle (levels 5-4);
+ * pwc_conv3x3_wino_workspace_bytes() bytes, shareable with pwc_conv2d_fwd's workspace on one stream; without it the layer runs unsplit */
+int64_t pwc_conv3x3_wino_workspace_bytes(int B, int Cin, int H, int W, int Cout, int dilation);
 
 /* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------
  * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch

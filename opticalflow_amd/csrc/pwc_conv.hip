@@ -84,6 +84,17 @@ inline pwc_conv::SplitPlan split_for(int B, int Cin, int H, int W, int Cout, int
 
 }  // namespace
 
+namespace pwc_conv {
+// partial [ksplit][B][Cout][plane] -> y (bias, LeakyReLU, optional residual), fixed z order; shared with pwc_conv_wino.hip
+int splitk_reduce(const float *partial, const float *bias, const float *residual, float *y, int B, int Cout, int plane, int ksplit,
+                  int64_t bsy, int64_t bsr, float slope, int do_leaky, hipStream_t st) {
+    const int64_t per_image = (int64_t)Cout * plane, total = per_image * B;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       partial, bias, residual, y, Cout, plane, ksplit, per_image, total, bsy, bsr, slope, do_leaky);
+    return pwc::check_launch("splitk_reduce_kernel");
+}
+}  // namespace pwc_conv
+
 extern "C" int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation) {
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return -1;
     const pwc_conv::SplitPlan sp = split_for(B, Cin, H, W, Cout, stride, dilation);
@@ -160,11 +171,8 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
         a.ksplit = sp.ksplit;
         a.cps = sp.cps;
         if (const int rc = pwc_conv::run_s1d1(a)) return rc;
-        const int64_t per_image = (int64_t)Cout * plane, total = per_image * B;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, a.stream,
-                           a.partial, a.bias, a.residual, a.y, Cout, (int)plane, sp.ksplit, per_image, total,
-                           a.bsy, a.bsr, a.slope, a.do_leaky);
-        return pwc::check_launch("splitk_reduce_kernel");
+        return pwc_conv::splitk_reduce(a.partial, a.bias, a.residual, a.y, B, Cout, (int)plane, sp.ksplit, a.bsy, a.bsr, a.slope,
+                                       a.do_leaky, a.stream);
     }
     if (stride == 1) {
         switch (dilation) {

@@ -22,6 +22,11 @@
 
 #include "pwc_common.h"
 
+namespace pwc_conv {
+int splitk_reduce(const float *partial, const float *bias, const float *residual, float *y, int B, int Cout, int plane, int ksplit,
+                  int64_t bsy, int64_t bsr, float slope, int do_leaky, hipStream_t st);      // pwc_conv.hip
+}
+
 namespace {
 
 using pwc::leaky;
@@ -375,7 +380,8 @@ template <int MT>
 __global__ void __launch_bounds__(kThreads8, 1)
 conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil, int co0) {
+                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil, int co0,
+                     int cps, float *__restrict__ part, int64_t zstride) {
     using G = Geo<MT>;
     constexpr int TG = G::kTG;
     constexpr int RS = (G::kRawElems + kThreads8 - 1) / kThreads8;        // dword LDS-DMAs per thread and chunk
@@ -427,7 +433,10 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     }
 
     const float *xb = x + (int64_t)b * bsx;
-    const int nchunks = (Cin + kCK - 1) / kCK;
+    // split-K (cps > 0): blockIdx.z owns the chunks [z*cps, (z+1)*cps) and writes its raw partial sums (At M A is linear) to
+    // part[z][b][Cout][H][W]; bias / LeakyReLU are applied by the fixed-order reduction (pwc_conv::splitk_reduce)
+    const int c_lo = cps ? (int)blockIdx.z * cps : 0;
+    const int nchunks = cps ? min((Cin + kCK - 1) / kCK - c_lo, cps) : (Cin + kCK - 1) / kCK;
     const int64_t uchunk = (int64_t)64 * CoutP;
     const float *ug = up + cb * 2;
     const int ubytes = (int)(uchunk - cb * 2) * 4;
@@ -437,12 +446,12 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     pwc::v4i32 rs_raw, rs_u;
     unsigned base_raw = 0, base_u = 0;
     auto setup_raw = [&](int chunk, int slot) {
-        const int c0 = chunk * kCK;
+        const int c0 = (c_lo + chunk) * kCK;
         rs_raw = pwc::make_rsrc(xb + (int64_t)c0 * plane, min(kCK, Cin - c0) * plane * 4);
         base_raw = __builtin_amdgcn_readfirstlane(lds_raw + slot * G::kRawRegion * 4);
     };
     auto setup_u = [&](int chunk, int slot) {
-        rs_u = pwc::make_rsrc(ug + (int64_t)chunk * uchunk, ubytes);
+        rs_u = pwc::make_rsrc(ug + (int64_t)(c_lo + chunk) * uchunk, ubytes);
         base_u = __builtin_amdgcn_readfirstlane(lds_u + slot * G::kUFloats * 4);
     };
     // transform: a thread makes ONE row i of V = Bt d B per unit (4 of the 16 positions) for one (channel, tile):
@@ -618,11 +627,24 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
                 // ph 0: M0 + M1 + M2(other);   ph 1: M1(other) - M2 - M3
                 tt[c] = ph ? (other - acc[c][j] - acc[4 + c][j]) : (acc[c][j] + acc[4 + c][j] + other);
             }
-            ya[jj] = tt[0] + tt[1] + tt[2] + bvs[j];
-            yb[jj] = tt[1] - tt[2] - tt[3] + bvs[j];
-            if (do_leaky) { ya[jj] = leaky(ya[jj], slope); yb[jj] = leaky(yb[jj], slope); }
+            const float bv = part ? 0.f : bvs[j];
+            ya[jj] = tt[0] + tt[1] + tt[2] + bv;
+            yb[jj] = tt[1] - tt[2] - tt[3] + bv;
+            if (do_leaky && !part) { ya[jj] = leaky(ya[jj], slope); yb[jj] = leaky(yb[jj], slope); }
         }
-        if (vec2 == 2) {
+        if (part) {
+            const int64_t pb = (int64_t)blockIdx.z * zstride + (int64_t)b * Cout * plane + (int64_t)oy * W + ox;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = 8 * r + jj;
+                const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+                if (inside && co < Cout) {
+                    float *o = part + pb + (int64_t)co * plane;
+                    o[0] = ya[jj];
+                    if (ox + dil < W) o[dil] = yb[jj];
+                }
+            }
+        } else if (vec2 == 2) {
             // 16-byte stores: the lanes of two neighbouring tiles (2 + 2 pixels of one row) swap halves -- the even lane ends up
             // with the four pixels of cout j, the odd lane with those of cout j + 1 -- so a lane issues 8 stores instead of 16
             // (the store tail of a workgroup is issue-bound: MI355X guide, "epilogue store tail")
@@ -659,7 +681,8 @@ inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
 
 template <int MT>
 int launch_wino(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int dil,
-                int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups) {
+                int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups,
+                int ksplit = 1, int cps = 0, float *part = nullptr) {
     using G = Geo<MT>;
     static pwc::LdsAttrOnce once;
     if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino_kernel<MT>), G::kSmemBytes,
@@ -678,32 +701,67 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
         if (const int rc = pwc::ensure_lds_attr(once8, reinterpret_cast<const void *>(&conv3x3_wino8_kernel<MT>), G::kSmemBytes,
                                                 "conv3x3_wino8_kernel"))
             return rc;
-        hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups), dim3(kThreads8), G::kSmemBytes, st,
-                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0);
+        hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups, (unsigned)ksplit), dim3(kThreads8), G::kSmemBytes, st,
+                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0,
+                           cps, part, (int64_t)B * Cout * H * W);
         pwc::note_kernel("conv3x3_wino8_kernel", MT, G::kTG, 1, dil, 1, 0);
         return pwc::check_launch("conv3x3_wino8_kernel");
     }
+    if (part) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv3x3_wino_fwd: split-K needs the eight-wave kernel");
     hipLaunchKernelGGL(conv3x3_wino_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups), dim3(kThreads), G::kSmemBytes, st,
                        x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0);
     pwc::note_kernel("conv3x3_wino_kernel", MT, G::kTG, 1, dil, 1, 0);
     return pwc::check_launch("conv3x3_wino_kernel");
 }
 
-}  // namespace
-
-// Does the Winograd route beat pwc_conv2d_fwd for this layer?  Measured rule (tools/bench_wino.py layers, batch 16): it needs
-// enough workgroups to cover the 256 CUs (one workgroup per CU, 4 waves), at least one full 32-row cout block, and -- with
-// dilation D, where it runs on the D*D pixel lattices of ceil(H/D) x ceil(W/D) -- tiles that are mostly inside the lattice.
-extern "C" int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout, int dilation) {
-    if (B <= 0 || Cin < 16 || H <= 0 || W <= 0 || Cout < 32 || dilation < 1 || dilation > 8) return 0;
+// Launch shape of a layer run with ONE cout-tile width (the widest that divides CoutP), and its split-K plan: a launch that leaves
+// most CUs idle (levels 5-4: 64-128 workgroups) is cut along Cin into ksplit slices of cps chunks (>= 8 chunks each: a tile costs
+// ~9 us outside its K loop), partial sums go to the caller's workspace, pwc_conv::splitk_reduce adds them in fixed order.
+struct WinoPlan { int mt, ksplit, cps; int64_t nwg; double fill; };
+WinoPlan wino_plan(int B, int Cin, int H, int W, int Cout, int dilation) {
     const int CoutP = cout_padded(Cout);
     const int mt = (CoutP % 128 == 0) ? 4 : (CoutP % 64 == 0) ? 2 : 1;
     const int gh = kGH * (4 / mt);
     const int Hs = (H + dilation - 1) / dilation, Ws = (W + dilation - 1) / dilation;
     const int tiles_x = (Ws + kTW - 1) / kTW, tiles_y = (Hs + gh - 1) / gh;
-    const int64_t nwg = (int64_t)B * tiles_x * tiles_y * dilation * dilation * (CoutP / (32 * mt));
-    const double fill = (double)Hs * Ws / ((double)tiles_y * gh * tiles_x * kTW);
-    return nwg >= 160 && fill >= 0.7;
+    WinoPlan p;
+    p.mt = mt;
+    p.nwg = (int64_t)B * tiles_x * tiles_y * dilation * dilation * (CoutP / (32 * mt));
+    p.fill = (double)Hs * Ws / ((double)tiles_y * gh * tiles_x * kTW);
+    const int nchunks = (Cin + kCK - 1) / kCK;
+    p.ksplit = 1;
+    p.cps = 0;
+    static const int knob = [] { const char *e = getenv("PWC_WINO_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
+    // measured (tools/bench_wino.py layers): with 64 workgroups (level 5 at batch 16) the split form only ties the direct kernel's own
+    // split-K; from ~100 (conv4_3: 128) it wins 1.35x
+    if (knob != 0 && p.nwg < 160 && p.nwg >= 96) {
+        int ks = (int)((320 + p.nwg - 1) / p.nwg);
+        if (knob > 0) ks = knob;
+        ks = ks < nchunks / 8 ? ks : nchunks / 8;
+        if (ks >= 2) {
+            p.cps = (nchunks + ks - 1) / ks;
+            p.ksplit = (nchunks + p.cps - 1) / p.cps;
+        }
+    }
+    return p;
+}
+
+}  // namespace
+
+// Does the Winograd route beat pwc_conv2d_fwd for this layer?  Measured rule (tools/bench_wino.py layers, batch 16): it needs
+// enough workgroups to cover the 256 CUs (one workgroup per CU, 8 waves; split-K counts), at least one full 32-row cout block,
+// and -- with dilation D, where it runs on the D*D pixel lattices of ceil(H/D) x ceil(W/D) -- tiles that are mostly inside the lattice.
+extern "C" int pwc_conv3x3_wino_preferred(int B, int Cin, int H, int W, int Cout, int dilation) {
+    if (B <= 0 || Cin < 16 || H <= 0 || W <= 0 || Cout < 32 || dilation < 1 || dilation > 8) return 0;
+    const WinoPlan p = wino_plan(B, Cin, H, W, Cout, dilation);
+    return p.nwg * p.ksplit >= 160 && p.fill >= 0.7;
+}
+
+/* bytes of workspace the split-K form of this layer wants (0: it does not split) */
+extern "C" int64_t pwc_conv3x3_wino_workspace_bytes(int B, int Cin, int H, int W, int Cout, int dilation) {
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || dilation < 1) return -1;
+    const WinoPlan p = wino_plan(B, Cin, H, W, Cout, dilation);
+    return p.ksplit > 1 ? (int64_t)p.ksplit * B * Cout * H * W * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int64_t pwc_conv3x3_wino_packed_bytes(int Cin, int Cout) {
@@ -722,7 +780,8 @@ extern "C" int pwc_conv3x3_wino_pack(const void *w, void *up, int Cin, int Cout,
 }
 
 extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *y, int B, int Cin, int H, int W, int Cout,
-                                    int dilation, unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
+                                    int dilation, unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride,
+                                    void *workspace, int64_t workspace_bytes, void *stream) {
     if (!x || !up || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: null pointer");
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: bad shape");
     if (dilation < 1 || dilation > 64) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: dilation %d", dilation);
@@ -741,6 +800,18 @@ extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *b
     // wider the cout tile, the fewer tile groups share a workgroup and the smaller the transform's share of the issue slots)
     static const int force_mt = [] { const char *e = getenv("PWC_WINO_MT"); return (e && *e) ? atoi(e) : 0; }();    // experiments
     const int nblk32 = CoutP / 32;
+    // split-K for launches that would leave most CUs idle (needs the caller's workspace; without it the layer runs unsplit)
+    const WinoPlan sp = wino_plan(B, Cin, H, W, Cout, dilation);
+    if (sp.ksplit > 1 && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 3u) &&
+        workspace_bytes >= (int64_t)sp.ksplit * B * Cout * plane * (int64_t)sizeof(float)) {
+        float *part = static_cast<float *>(workspace);
+        int rc;
+        if (sp.mt == 4) rc = launch_wino<4>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32 / 4, sp.ksplit, sp.cps, part);
+        else if (sp.mt == 2) rc = launch_wino<2>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32 / 2, sp.ksplit, sp.cps, part);
+        else rc = launch_wino<1>(xf, uf, bf, yf, B, Cin, H, W, Cout, dilation, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, nblk32, sp.ksplit, sp.cps, part);
+        if (rc) return rc;
+        return pwc_conv::splitk_reduce(part, bf, nullptr, yf, B, Cout, (int)plane, sp.ksplit, y_bstride, 0, leaky_slope, do_leaky, st);
+    }
     int co0 = 0;
     if (force_mt == 1 || force_mt == 2) {
         if (force_mt == 2 && nblk32 % 2 == 0)

@@ -144,6 +144,8 @@ class PwcPlan:
                 cin = level_in_channels(l, self.nd)
                 for co in DENSE_OUT + (2,):
                     need = max(need, ops.conv3x3_workspace_bytes(B, cin, h, w, co))
+                    if self.wino and co >= 32:
+                        need = max(need, ops.conv3x3_wino_workspace_bytes(B, cin, h, w, co))
                     cin += co if co != 2 else 0
             if need:
                 self.workspace = torch.empty((need // 4,), **kw)
@@ -167,7 +169,8 @@ class PwcPlan:
         if (self.wino and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and residual is None and x.dtype == torch.float32
                 and ops.conv3x3_wino_preferred(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], dilation)):
             # Winograd F(2x2,3x3) on the matrix cores: 2.25x fewer MFMA passes for the same fp32 convolution
-            ops.conv3x3_wino(x, self.wino_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out, dilation=dilation)
+            ops.conv3x3_wino(x, self.wino_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out, dilation=dilation,
+                             workspace=self.workspace)
             self.conv_macs["executed"] += macs * 16 // 36         # multiplications the matrix cores actually perform
             return
         self.conv_macs["executed"] += macs

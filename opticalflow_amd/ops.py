@@ -292,8 +292,16 @@ def pack_conv3x3_wino(weight: torch.Tensor) -> torch.Tensor:
     return up
 
 
+def conv3x3_wino_workspace_bytes(B: int, cin: int, H: int, W: int, cout: int, dilation: int = 1) -> int:
+    """Scratch bytes the split-K form of this layer wants (0 = it does not split)."""
+    n = _lib.load().pwc_conv3x3_wino_workspace_bytes(B, cin, H, W, cout, dilation)
+    if n < 0:
+        raise ValueError("bad conv geometry")
+    return int(n)
+
+
 def conv3x3_wino(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cout: int, leaky_slope: Optional[float] = 0.1,
-                 out: Optional[torch.Tensor] = None, dilation: int = 1) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, dilation: int = 1, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3 / stride 1 convolution (padding = dilation) + bias (+ LeakyReLU) by Winograd F(2x2,3x3) on the matrix cores (fp32)."""
     lib = _lib.load()
     bsx = _plane_dense(x, "x")
@@ -310,9 +318,15 @@ def conv3x3_wino(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cou
         raise ValueError("packed Winograd filters do not match Cin=%d Cout=%d (have %d B, need %d B)" % (cin, cout, upacked.numel() * 4, need))
     if bias.dtype != torch.float32 or bias.numel() != cout or bias.device != x.device or not bias.is_contiguous():
         raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
+    ws_ptr, ws_bytes = 0, 0
+    if workspace is not None:
+        if workspace.device != x.device or not workspace.is_contiguous():
+            raise ValueError("workspace must be a contiguous tensor on %s" % x.device)
+        ws_ptr, ws_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     with torch.cuda.device(x.device):
         rc = lib.pwc_conv3x3_wino_fwd(x.data_ptr(), upacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout, dilation,
-                                      FLAG_ACT_LEAKY if leaky_slope is not None else 0, float(leaky_slope or 0.0), bsx, bsy, _stream(x))
+                                      FLAG_ACT_LEAKY if leaky_slope is not None else 0, float(leaky_slope or 0.0), bsx, bsy,
+                                      ws_ptr, ws_bytes, _stream(x))
     check(rc, "pwc_conv3x3_wino_fwd")
     return out
 

@@ -756,3 +756,29 @@ def test_forward_winograd_route_matches_direct_route(gpu_device, monkeypatch):
         assert (plan.conv_macs["executed"] < plan.conv_macs["direct"]) == (flag == "1")
     epe = (flows["1"] - flows["0"]).pow(2).sum(1).sqrt().mean().item()
     assert epe < 2e-5, epe
+
+
+@pytest.mark.gpu
+def test_conv3x3_winograd_split_k(gpu_device):
+    """A launch of 32..159 workgroups is cut along Cin (levels 5-4 at batch 16); partial sums through the caller's workspace and
+    a fixed-order reduction.  Same bound as the unsplit kernel; without a workspace the layer runs unsplit."""
+    from opticalflow_amd import ops
+    B, cin, cout, H, W = 4, 80, 128, 32, 128
+    need = ops.conv3x3_wino_workspace_bytes(B, cin, H, W, cout)
+    assert need == 2 * B * cout * H * W * 4                      # 128 workgroups, 20 chunks -> 2 slices of 10
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1)
+    xd, bd = x.to(gpu_device), b.to(gpu_device)
+    up = ops.pack_conv3x3_wino(w.to(gpu_device))
+    ws = torch.empty(need // 4, device=gpu_device)
+    split = ops.conv3x3_wino(xd, up, bd, cout, workspace=ws).cpu()
+    again = ops.conv3x3_wino(xd, up, bd, cout, workspace=ws).cpu()
+    unsplit = ops.conv3x3_wino(xd, up, bd, cout).cpu()
+    tol = 3e-6 * (cin * 9) ** 0.5
+    assert (split.double() - ref).abs().max().item() <= tol and (unsplit.double() - ref).abs().max().item() <= tol
+    assert torch.equal(split, again)                              # fixed-order reduction: bit-reproducible
+    small = torch.empty(16, device=gpu_device)                    # too small a workspace: unsplit, same result as without one
+    assert torch.equal(ops.conv3x3_wino(xd, up, bd, cout, workspace=small).cpu(), unsplit)

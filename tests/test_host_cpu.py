@@ -49,14 +49,18 @@ def test_abi_argument_errors_without_gpu():
     # Winograd route: filter image = [chunks of 4 cin][16 positions][2][CoutP][2] floats; argument checks; the preference rule
     assert lib.pwc_conv3x3_wino_packed_bytes(565, 128) == 142 * 64 * 128 * 4
     assert lib.pwc_conv3x3_wino_packed_bytes(5, 7) == 2 * 64 * 32 * 4 and lib.pwc_conv3x3_wino_packed_bytes(0, 7) == -1
-    assert lib.pwc_conv3x3_wino_fwd(None, None, None, None, 1, 4, 8, 8, 32, 1, 0, 0.0, 1024, 2048, None) == -1
+    assert lib.pwc_conv3x3_wino_fwd(None, None, None, None, 1, 4, 8, 8, 32, 1, 0, 0.0, 1024, 2048, None, 0, None) == -1
     assert b"null pointer" in lib.pwc_last_error()
     four = [ctypes.c_void_p(4096)] * 4
-    assert lib.pwc_conv3x3_wino_fwd(*four, 1, 4, 8, 8, 32, 0, 0, 0.0, 1024, 2048, None) == -1 and b"dilation" in lib.pwc_last_error()
-    assert lib.pwc_conv3x3_wino_fwd(*four, 1, 4, 8, 8, 32, 1, 0, 0.0, 8, 2048, None) == -1 and b"batch stride" in lib.pwc_last_error()
+    assert lib.pwc_conv3x3_wino_fwd(*four, 1, 4, 8, 8, 32, 0, 0, 0.0, 1024, 2048, None, 0, None) == -1 and b"dilation" in lib.pwc_last_error()
+    assert lib.pwc_conv3x3_wino_fwd(*four, 1, 4, 8, 8, 32, 1, 0, 0.0, 8, 2048, None, 0, None) == -1 and b"batch stride" in lib.pwc_last_error()
     pref = lib.pwc_conv3x3_wino_preferred
     assert pref(16, 565, 112, 256, 128, 1) == 1 and pref(16, 128, 112, 256, 128, 4) == 1          # dc_conv1, dc_conv3
     assert pref(16, 497, 7, 16, 32, 1) == 0 and pref(32, 16, 224, 512, 16, 1) == 0                # level 6; Cout 16
+    wsb = lib.pwc_conv3x3_wino_workspace_bytes
+    assert pref(16, 533, 28, 64, 64, 1) == 1 and wsb(16, 533, 28, 64, 64, 1) == 3 * 16 * 64 * 28 * 64 * 4        # conv4_3: 128 tiles x 3 Cin slices
+    assert pref(16, 341, 14, 32, 128, 1) == 0 and wsb(16, 341, 14, 32, 128, 1) == 0                 # level 5 (64 tiles) stays on the direct kernel
+    assert wsb(16, 565, 112, 256, 128, 1) == 0                                                    # a full grid does not split
     assert pref(16, 96, 112, 256, 64, 16) == 0 and pref(1, 565, 112, 256, 128, 1) == 1            # 7x16 lattices; batch 1 at level 2
     # split filters (flow heads) exist for Cout <= 16 only
     assert lib.pwc_conv3x3_f16_pack_split(ctypes.c_void_p(4096), ctypes.c_void_p(4096), 64, 32, None) == -2

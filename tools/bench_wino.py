@@ -89,7 +89,9 @@ if mode == "layers":       # every stride-1 / dilation-1 3x3 layer of the forwar
         y, y0 = torch.empty(B, cout, H, W, device=dev), torch.empty(B, cout, H, W, device=dev)
         nws = ops.conv3x3_workspace_bytes(B, cin, H, W, cout)
         ws = torch.empty(max(nws, 4) // 4, device=dev)
-        tw = t2(lambda: ops.conv3x3_wino(x, up, b, cout, out=y, dilation=D))
+        nww = ops.conv3x3_wino_workspace_bytes(B, cin, H, W, cout, D)
+        wws = torch.empty(max(nww, 4) // 4, device=dev)
+        tw = t2(lambda: ops.conv3x3_wino(x, up, b, cout, out=y, dilation=D, workspace=wws if nww else None))
         td = t2(lambda: ops.conv3x3(x, wp, b, cout, dilation=D, out=y0, workspace=ws if (nws and D == 1) else None))
         print("%-12s B%-2d %3d->%3d @%3dx%-3d: wino %7.1f us   direct %7.1f us   x%.2f   preferred=%d   max diff %.1e" %
               (name, B, cin, cout, H, W, tw * 1e3, td * 1e3, td / tw, ops.conv3x3_wino_preferred(B, cin, H, W, cout, D), (y - y0).abs().max().item()), flush=True)
