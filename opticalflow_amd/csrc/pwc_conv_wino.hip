@@ -583,6 +583,9 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
         unit_math(t);
         unit_store(t, 0);
     }
+#ifndef PWC_WINO_NO_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched wave of each SIMD loses every issue arbitration otherwise
+#endif
     int r3 = 0;
     int k = 0;
     for (; k + 3 < nchunks; ++k) {
