@@ -682,6 +682,11 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
 
 inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
 
+inline int wino_waves() {               // PWC_WINO_WAVES=4: the four-wave kernel (comparison / fallback; no split-K)
+    static const int v = [] { const char *e = getenv("PWC_WINO_WAVES"); return (e && *e) ? atoi(e) : 8; }();
+    return v;
+}
+
 template <int MT>
 int launch_wino(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int dil,
                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups,
@@ -698,7 +703,7 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: grid too large");
     int vec2 = dil == 1 && (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
     if (vec2 && (W % 4 == 0) && (bsy % 4 == 0) && !(reinterpret_cast<uintptr_t>(y) & 15u)) vec2 = 2;      // 16-byte stores (8-wave kernel)
-    static const int waves = [] { const char *e = getenv("PWC_WINO_WAVES"); return (e && *e) ? atoi(e) : 8; }();
+    const int waves = wino_waves();
     if (waves == 8) {
         static pwc::LdsAttrOnce once8;
         if (const int rc = pwc::ensure_lds_attr(once8, reinterpret_cast<const void *>(&conv3x3_wino8_kernel<MT>), G::kSmemBytes,
@@ -805,7 +810,7 @@ extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *b
     const int nblk32 = CoutP / 32;
     // split-K for launches that would leave most CUs idle (needs the caller's workspace; without it the layer runs unsplit)
     const WinoPlan sp = wino_plan(B, Cin, H, W, Cout, dilation);
-    if (sp.ksplit > 1 && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 3u) &&
+    if (sp.ksplit > 1 && wino_waves() == 8 && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 3u) &&
         workspace_bytes >= (int64_t)sp.ksplit * B * Cout * plane * (int64_t)sizeof(float)) {
         float *part = static_cast<float *>(workspace);
         int rc;
