@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` as a
+child process); under torch.distributed.run it is one of the ranks.
+
 A step = one PWCDCNet.forward over this rank's batch of B synthetic image pairs already resident in
 HBM (full HIP path: correlation, warp, MFMA implicit-GEMM convs; HIP-graph replay), plus -- for N>1 --
 the gather of the flow fields to rank 0.  N>1 is launched by torch.distributed.run, one process per
@@ -327,6 +331,23 @@ def bench_kitti(args, rank, world, dev, rehearse):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves, as a CHILD process and before this
+    process has touched the GPU (no exec: replacing a process that initialised HIP is not allowed on the pool, and nothing here
+    has).  The child's stdout is ours -- rank 0's single JSON line passes through -- and its exit code becomes ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("--gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,9 +375,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            return self_launch(args.gpus)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch.distributed as dist

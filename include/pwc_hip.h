@@ -115,7 +115,12 @@ int pwc_warp_fwd(const void *x, const void *flo, void *out,
  * workspace (device, 8-byte aligned, >= pwc_warp_bwd_workspace_bytes): the scatter accumulates 64-bit FIXED-POINT integers
  * there (integer addition is associative -> bit-reproducible grad_x whatever order the atomics arrive in; resolution 2^-40
  * of the largest |grad_out|) and grad_x is written once at the end.  workspace == NULL: grad_x is zeroed and accumulated
- * with float atomics like torch's grid_sample backward (summation order, hence the last bits, not fixed). */
+ * with float atomics like torch's grid_sample backward (summation order, hence the last bits, not fixed).
+ * Limits of the fixed-point form: (1) one contribution is at most 2^41 in magnitude, so a source pixel that collects more
+ * than 2^22 (4 194 304) contributions of the largest |grad_out| would wrap its int64 -- more output pixels than that sampling
+ * ONE source pixel; (2) a non-finite grad_out (Inf / NaN) has no fixed-point form: the call then falls back, on the device and
+ * without synchronising, to the float-atomic accumulation for the whole tensor, so Inf / NaN reach grad_x exactly as in the
+ * float path (that call is not bit-reproducible). */
 int64_t pwc_warp_bwd_workspace_bytes(int B, int C, int H, int W);
 int pwc_warp_bwd(const void *x, const void *flo, const void *grad_out, void *grad_x, void *grad_flo,
                  int B, int C, int H, int W,

@@ -27,8 +27,22 @@ from torch.autograd import Function
 
 from . import ops
 
+import sys
+
 # Same global switch name as the reference (correlation.py:9).  Off by default.
 USE_ONNX_CORRELATION = False
+
+_SHIM = "models.correlation_package.correlation"
+
+
+def onnx_correlation_enabled() -> bool:
+    """True when the reference's export switch is on, set EITHER here or -- the way the reference's own callers do it
+    (pth2onnx.py:44-46, onnx_pth_compare.py:91-93: ``corr_mod.USE_ONNX_CORRELATION = True`` on the module they import as
+    ``models.correlation_package.correlation``) -- as a plain module attribute of the import-path shim."""
+    if USE_ONNX_CORRELATION:
+        return True
+    shim = sys.modules.get(_SHIM)
+    return bool(shim is not None and shim.__dict__.get("USE_ONNX_CORRELATION", False))
 
 
 def correlation_traceable(input1, input2, pad_size, kernel_size, max_displacement, stride1, stride2,
@@ -92,7 +106,7 @@ class Correlation(nn.Module):
             self.corr_multiply, self.normalize)
 
     def forward(self, input1, input2):
-        if USE_ONNX_CORRELATION:
+        if onnx_correlation_enabled():
             return correlation_traceable(input1, input2, self.pad_size, self.kernel_size, self.max_displacement,
                                          self.stride1, self.stride2, self.corr_multiply, self.normalize)
         if torch.is_grad_enabled() and (input1.requires_grad or input2.requires_grad):

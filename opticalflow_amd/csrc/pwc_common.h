@@ -35,8 +35,12 @@ template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // float -> half with saturation: a value past the half range becomes +-65504 instead of inf (which the next layer's
-// fp32 accumulation would turn into NaN through inf - inf); NaN stays NaN
-__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+// fp32 accumulation would turn into NaN through inf - inf).  NaN stays NaN: v_med3_f32 alone would launder a NaN operand into
+// -65504 (with a quiet NaN it returns the min3 of its operands, and v_min returns the non-NaN one), so NaN is selected explicitly
+// -- a NaN from bad weights or inputs must stay visible to the caller's isfinite checks.
+__device__ __forceinline__ _Float16 sat_half(float v) {
+    return (_Float16)(v != v ? v : __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f));
+}
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -9,11 +9,11 @@
 //   U = G g Gt is computed once per model (pwc_conv3x3_wino_pack) and laid out the way the kernel's LDS wants it;
 //   V = Bt d B is computed in the kernel from the raw input tile (LDS -> registers -> LDS), hidden under the MFMAs;
 //   v_mfma_f32_32x32x2_f32: A = U_p (32 couts x 2 cin), B = V_p (2 cin x 32 tiles), D = 32 couts x 32 tiles.
-// A wave owns ONE 32-cout block x ONE group of 32 tiles (4 rows x 32 columns of output) and ALL 16 positions
-// (16 x 16 = 256 accumulator registers), so the output transform At M A happens in the wave's own registers: no exchange.
-// Workgroup = 4 waves = MT cout blocks x (4/MT) tile groups; Cin is consumed in chunks of 4 channels (two MFMA k-steps):
-//     iteration k:  barrier | 32 MFMAs on U(k), V(k), with -- one micro-step in the shadow of each MFMA -- the LDS-DMA of
-//                   raw(k+3) and U(k+2) and the transform raw(k+1) -> V(k+1)
+// A PAIR of waves owns ONE 32-cout block x ONE group of 32 tiles (4 rows x 32 columns of output): 8 of the 16 positions each
+// (8 x 16 = 128 accumulator registers); the output transform At M A swaps one row of M between the two through LDS.
+// Workgroup = 8 waves = MT cout blocks x (4/MT) tile groups; Cin is consumed in chunks of 4 channels (two MFMA k-steps):
+//     iteration k:  barrier | 16 MFMAs per wave on U(k), V(k), with -- one micro-step in the shadow of each MFMA -- the LDS-DMA
+//                   of raw(k+3) and U(k+2) and the transform raw(k+1) -> V(k+1)
 // LDS: raw [3][4][rows+2][34], U [3][16][2][32*MT][2], V [2][tile groups][16][2][32][2]  (98-124 KiB, one workgroup per CU).
 // Zero padding, ragged edges and the ragged last channel chunk come from the buffer range check (0 into LDS).
 #include <stdlib.h>
@@ -90,283 +90,10 @@ wino_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, i
     up[i] = v;
 }
 
-template <int MT>
-__global__ void __launch_bounds__(kThreads, 1)
-conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
-                    float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                    int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil, int co0) {
-    using G = Geo<MT>;
-    constexpr int TG = G::kTG;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *raw = smem;                                  // [3][kRawRegion]
-    float *ubuf = smem + 3 * G::kRawRegion;             // [3][kUFloats]
-    float *vbuf = ubuf + 3 * G::kUFloats;               // [2][kVFloats]
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int col = lane & 31;
-    const int kh = lane >> 5;
-
-    int bid = blockIdx.x;
-    // workgroups i, i+8, ... share an XCD: give each XCD a contiguous run of tiles so that halo re-reads hit its L2
-    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
-    // dilation D: the pixels with (y mod D, x mod D) = (ry, rx) form a lattice on which the layer is an ordinary 3x3
-    // convolution; a workgroup works on one such lattice (innermost in the block index, so the D*D lattices of a region
-    // run together on one XCD) and only its global addresses know about D.  All tile coordinates below are lattice coordinates.
-    const int sub = bid % (dil * dil);
-    bid /= dil * dil;
-    const int ry = sub / dil, rx = sub % dil;
-    const int tx = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
-    const int cb = co0 + (int)blockIdx.y * G::kCoutT;         // first cout of this workgroup
-    const int ox0 = tx * kTW;
-    const int oy0 = ty * (kGH * TG);
-    const int plane = H * W;
-
-    // ---- per-lane DMA source offsets, computed once --------------------------------------------------
-    unsigned raw_off[G::kRawSlots];
-#pragma unroll
-    for (int j = 0; j < G::kRawSlots; ++j) {
-        const int i = j * kThreads + tid;
-        const int c = i / G::kRawPlane;
-        const int rem = i % G::kRawPlane;
-        const int iy = ry + dil * (oy0 - 1 + rem / kRawW);
-        const int ix = rx + dil * (ox0 - 1 + rem % kRawW);
-        const bool ok = (i < G::kRawElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
-        raw_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
-    }
-    unsigned u_off[G::kUSlots];
-#pragma unroll
-    for (int j = 0; j < G::kUSlots; ++j) {
-        const int p = j * kThreads + tid;                   // 16-byte piece of the [pos*2+kh][cout][step] image
-        const int row = p / (16 * MT);
-        const int q = p % (16 * MT);
-        u_off[j] = (unsigned)(row * CoutP * 2 + q * 4) * 4u;
-    }
-
-    const float *xb = x + (int64_t)b * bsx;
-    const int nchunks = (Cin + kCK - 1) / kCK;
-    const int64_t uchunk = (int64_t)64 * CoutP;              // floats per chunk of the packed image
-    const float *ug = up + cb * 2;
-    const int ubytes = (int)(uchunk - cb * 2) * 4;
-    const unsigned lds_raw = pwc::lds_addr(raw) + wave * 256;         // + slot*kRawRegion*4 + j*1024
-    const unsigned lds_u = pwc::lds_addr(ubuf) + wave * 1024;         // + slot*kUFloats*4 + j*4096
-
-    // ---- one chunk = 32 MFMA slots; the rest of the iteration's work is dealt out one micro-step per slot so that it
-    // issues in the 64-cycle shadow of the preceding MFMA: the LDS-DMA of raw(k+3) and U(k+2), the operand reads of the
-    // next group of four positions, and the transform Bt d B of raw(k+1) (loads / adds / writes of one unit per slot).
-    constexpr int RS = G::kRawSlots, US = G::kUSlots;
-    pwc::v4i32 rs_raw, rs_u;
-    unsigned base_raw = 0, base_u = 0;
-    auto setup_raw = [&](int chunk, int slot) {
-        const int c0 = chunk * kCK;
-        rs_raw = pwc::make_rsrc(xb + (int64_t)c0 * plane, min(kCK, Cin - c0) * plane * 4);
-        base_raw = __builtin_amdgcn_readfirstlane(lds_raw + slot * G::kRawRegion * 4);
-    };
-    auto setup_u = [&](int chunk, int slot) {
-        rs_u = pwc::make_rsrc(ug + (int64_t)chunk * uchunk, ubytes);
-        base_u = __builtin_amdgcn_readfirstlane(lds_u + slot * G::kUFloats * 4);
-    };
-    // transform unit t of this thread: (half, channel, tile); half 0 makes V rows 0,1, half 1 rows 2,3
-    f32x2 d[TG][3][2];
-    float vo8[TG][8];
-    auto unit_src = [&](int t, int rslot) -> const float * {
-        const int u = t * kThreads + tid;
-        const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, half = u / (128 * TG);
-        const int tgi = n >> 5, tile = n & 31;
-        return raw + rslot * G::kRawRegion + c * G::kRawPlane + (kGH * tgi + 2 * (tile >> 4) + half) * kRawW + 2 * (tile & 15);
-    };
-    auto unit_dst = [&](int t, int vslot) -> float * {
-        const int u = t * kThreads + tid;
-        const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, half = u / (128 * TG);
-        const int tgi = n >> 5, tile = n & 31;
-        return vbuf + vslot * G::kVFloats + ((tgi * 16 + half * 8) * 2 + (c >> 1)) * 64 + tile * 2 + (c & 1);
-    };
-    auto unit_load = [&](int t, int rslot) {
-        const float *p = unit_src(t, rslot);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            d[t][r][0] = *reinterpret_cast<const f32x2 *>(p + r * kRawW);
-            d[t][r][1] = *reinterpret_cast<const f32x2 *>(p + r * kRawW + 2);
-        }
-    };
-    auto unit_math = [&](int t) {
-        const int half = (t * kThreads + tid) / (128 * TG);
-        float w0[4], w1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float da = d[t][0][j >> 1][j & 1], db = d[t][1][j >> 1][j & 1], dc = d[t][2][j >> 1][j & 1];
-            // half 0: rows (d0,d1,d2): Bt rows 0,1 = d0-d2, d1+d2.   half 1: rows (d1,d2,d3): Bt rows 2,3 = d2-d1, d1-d3
-            w0[j] = half ? (db - da) : (da - dc);
-            w1[j] = half ? (da - dc) : (db + dc);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float *wr = i ? w1 : w0;
-            vo8[t][i * 4 + 0] = wr[0] - wr[2];
-            vo8[t][i * 4 + 1] = wr[1] + wr[2];
-            vo8[t][i * 4 + 2] = wr[2] - wr[1];
-            vo8[t][i * 4 + 3] = wr[1] - wr[3];
-        }
-    };
-    auto unit_store = [&](int t, int vslot, int lo) {
-        float *vo = unit_dst(t, vslot);
-#pragma unroll
-        for (int i = lo; i < lo + 4; ++i) vo[i * 128] = vo8[t][i];
-    };
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[p][j] = 0.f;
-
-    const int blk = wave % MT, tgw = wave / MT;
-    const int ua_off = (kh * G::kCoutT + blk * 32 + col) * 2;
-    const int vb_off = tgw * G::kVGroup + (kh * 32 + col) * 2;
-
-    f32x2 a2[2][4], b2[2][4];                 // operand sets: groups 0, 2 use set 0; groups 1, 3 set 1
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a2[1][i] = b2[1][i] = (f32x2){0.f, 0.f};     // "group 3 of chunk -1" adds 0 * 0
-
-    // FULL: every piece of the iteration exists (k + 3 < nchunks); otherwise each piece is guarded.
-    // The iteration is rotated by one group: its first 8 MFMAs are positions 12..15 of chunk k-1, whose operands were read
-    // into registers before the barrier, so the matrix pipe restarts right behind the barrier while everything else of the
-    // iteration -- operand reads of chunk k, descriptors, LDS-DMA, transform -- issues in MFMA shadows.
-    auto iteration = [&](int k, int r3, auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        // slots of the rings: raw(k+3) -> r3 (= k % 3), raw(k+1) in (k+1) % 3; U(k) in k % 3, U(k+2) -> (k+2) % 3
-        const int r1 = (r3 == 2) ? 0 : r3 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
-        const bool do_raw = FULL || (k + 3 < nchunks), do_u = FULL || (k + 2 < nchunks), do_tr = FULL || (k + 1 < nchunks);
-        if (FULL || k + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RS + US) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const float *ua = ubuf + r3 * G::kUFloats + ua_off;
-        const float *vb = vbuf + (k & 1) * G::kVFloats + vb_off;
-        constexpr int kDma0 = 3;                                // first LDS-DMA slot (descriptors are built in slot 2)
-        constexpr int kTr0 = 4, kTrStep = (TG == 4) ? 6 : 8;    // unit t: loads in slot kTr0 + t*kTrStep, adds 2 later, writes 3 and 4 later
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            const int q = (s >> 3) - 1, i = s & 7;              // q = -1: group 3 of the previous chunk (operand set 1)
-            const int pq = (q < 0) ? 3 : q;
-            acc[4 * pq + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[pq & 1][i & 3][i >> 2], b2[pq & 1][i & 3][i >> 2], acc[4 * pq + (i & 3)], 0, 0, 0);
-            if (s < 2) {                                        // operands of group 0 of this chunk
-#pragma unroll
-                for (int j = 2 * s; j < 2 * s + 2; ++j) {
-                    a2[0][j] = *reinterpret_cast<const f32x2 *>(ua + j * (2 * G::kCoutT * 2));
-                    b2[0][j] = *reinterpret_cast<const f32x2 *>(vb + j * 128);
-                }
-            }
-            if (i < 4 && q >= 0) {                              // operands of group q+1 during group q
-                a2[(q + 1) & 1][i] = *reinterpret_cast<const f32x2 *>(ua + (4 * (q + 1) + i) * (2 * G::kCoutT * 2));
-                b2[(q + 1) & 1][i] = *reinterpret_cast<const f32x2 *>(vb + (4 * (q + 1) + i) * 128);
-            }
-            if (s == 2) {
-                if (do_raw) setup_raw(k + 3, r3);
-                if (do_u) setup_u(k + 2, r2);
-            }
-            if (s >= kDma0 && s < kDma0 + RS) {
-                if (do_raw) pwc::dma_b32(rs_raw, base_raw + (s - kDma0) * kThreads * 4, raw_off[s - kDma0]);
-            } else if (s >= kDma0 + RS && s < kDma0 + RS + US) {
-                if (do_u) pwc::dma_b128(rs_u, base_u + (s - kDma0 - RS) * kThreads * 16, u_off[s - kDma0 - RS]);
-            }
-            if (do_tr) {
-#pragma unroll
-                for (int t = 0; t < TG; ++t) {
-                    const int ph = s - kTr0 - t * kTrStep;
-                    if (ph == 0) unit_load(t, r1);
-                    else if (ph == 2) unit_math(t);
-                    else if (ph == 3) unit_store(t, (k + 1) & 1, 0);
-                    else if (ph == 4) unit_store(t, (k + 1) & 1, 4);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // prologue: raw(0) -> V(0); then the two groups the loop expects in flight: {raw(1), U(0)} and {raw(2), U(1)}
-    setup_raw(0, 0);
-#pragma unroll
-    for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads * 4, raw_off[j]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < TG; ++t) {
-        unit_load(t, 0);
-        unit_math(t);
-        unit_store(t, 0, 0);
-        unit_store(t, 0, 4);
-    }
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-        if (gq + 1 < nchunks) {
-            setup_raw(gq + 1, gq + 1);
-#pragma unroll
-            for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads * 4, raw_off[j]);
-        }
-        if (gq < nchunks) {
-            setup_u(gq, gq);
-#pragma unroll
-            for (int j = 0; j < US; ++j) pwc::dma_b128(rs_u, base_u + j * kThreads * 16, u_off[j]);
-        }
-    }
-    int r3 = 0;
-    int k = 0;
-    for (; k + 3 < nchunks; ++k) {
-        iteration(k, r3, std::true_type{});
-        r3 = (r3 == 2) ? 0 : r3 + 1;
-    }
-    for (; k < nchunks; ++k) {
-        iteration(k, r3, std::false_type{});
-        r3 = (r3 == 2) ? 0 : r3 + 1;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)               // group 3 of the last chunk
-        acc[12 + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][i & 3][i >> 2], b2[1][i & 3][i >> 2], acc[12 + (i & 3)], 0, 0, 0);
-
-    // ---- output transform At M A in registers, bias, LeakyReLU, 8-byte stores --------------------------
-    const int oy = ry + dil * (oy0 + kGH * tgw + 2 * (col >> 4));
-    const int ox = rx + dil * (ox0 + 2 * (col & 15));
-    if (oy >= H || ox >= W) return;
-    const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
-    float bvs[16];                            // one batch of loads, one wait (16 dependent round trips otherwise)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) bvs[j] = bias[min(cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-        if (co >= Cout) continue;
-        float t0[4], t1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t0[c] = acc[c][j] + acc[4 + c][j] + acc[8 + c][j];
-            t1[c] = acc[4 + c][j] - acc[8 + c][j] - acc[12 + c][j];
-        }
-        const float bv = bvs[j];
-        float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
-        float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
-        if (do_leaky) { y00 = leaky(y00, slope); y01 = leaky(y01, slope); y10 = leaky(y10, slope); y11 = leaky(y11, slope); }
-        float *o = y + obase + (int64_t)co * plane;
-        if (vec2) {
-            *reinterpret_cast<f32x2 *>(o) = (f32x2){y00, y01};
-            if (oy + 1 < H) *reinterpret_cast<f32x2 *>(o + W) = (f32x2){y10, y11};
-        } else {
-            o[0] = y00;
-            if (ox + dil < W) o[dil] = y01;
-            if (oy + dil < H) {
-                o[(int64_t)dil * W] = y10;
-                if (ox + dil < W) o[(int64_t)dil * W + dil] = y11;
-            }
-        }
-    }
-}
-
-// ---- the same algorithm with EIGHT waves (two per SIMD) --------------------------------------------------------------
+// ---- EIGHT waves (two per SIMD) ------------------------------------------------------------------------------------------
 // With one wave per SIMD every instruction that is not an MFMA competes with the MFMAs for the wave's single in-order issue
-// slot: the four-wave kernel above keeps the matrix pipe 75 % (128-cout layers) to 55 % (32-cout layers) busy.  Here the 16
+// slot (a four-wave form with 256 accumulators per wave was measured in round 2: matrix pipe 75 % busy on 128-cout layers, 55 %
+// on 32-cout layers, 3-9 % slower; removed in round 3).  Here the 16
 // positions of a (cout block, tile group) pair are split between two waves (8 positions = 128 accumulator registers each), so
 // the workgroup has 8 waves, two per SIMD, and one wave's LDS-DMA / transform / operand reads issue while the other wave's
 // MFMAs run.  The price is an exchange at the end: At M A needs all four rows of M, each wave of a pair holds two; the
@@ -399,8 +126,12 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     const int kh = lane >> 5;
 
     int bid = blockIdx.x;
+    // workgroups i, i+8, ... share an XCD: give each XCD a contiguous run of tiles so that halo re-reads hit its L2
     if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
-    const int sub = bid % (dil * dil);                  // pixel lattice of a dilated layer (see conv3x3_wino_kernel)
+    // dilation D: the pixels with (y mod D, x mod D) = (ry, rx) form a lattice on which the layer is an ordinary 3x3
+    // convolution; a workgroup works on one such lattice (innermost in the block index, so the D*D lattices of a region
+    // run together on one XCD) and only its global addresses know about D.  All tile coordinates below are lattice coordinates.
+    const int sub = bid % (dil * dil);                  // pixel lattice of a dilated layer
     bid /= dil * dil;
     const int ry = sub / dil, rx = sub % dil;
     const int tx = bid % tiles_x;
@@ -682,20 +413,11 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
 
 inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
 
-inline int wino_waves() {               // PWC_WINO_WAVES=4: the four-wave kernel (comparison / fallback; no split-K)
-    static const int v = [] { const char *e = getenv("PWC_WINO_WAVES"); return (e && *e) ? atoi(e) : 8; }();
-    return v;
-}
-
 template <int MT>
 int launch_wino(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int dil,
                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups,
                 int ksplit = 1, int cps = 0, float *part = nullptr) {
     using G = Geo<MT>;
-    static pwc::LdsAttrOnce once;
-    if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino_kernel<MT>), G::kSmemBytes,
-                                            "conv3x3_wino_kernel"))
-        return rc;
     const int CoutP = cout_padded(Cout);
     const int Hs = (H + dil - 1) / dil, Ws = (W + dil - 1) / dil;            // the largest of the D*D lattices
     const int tiles_x = (Ws + kTW - 1) / kTW, tiles_y = (Hs + kGH * G::kTG - 1) / (kGH * G::kTG);
@@ -703,23 +425,15 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: grid too large");
     int vec2 = dil == 1 && (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
     if (vec2 && (W % 4 == 0) && (bsy % 4 == 0) && !(reinterpret_cast<uintptr_t>(y) & 15u)) vec2 = 2;      // 16-byte stores (8-wave kernel)
-    const int waves = wino_waves();
-    if (waves == 8) {
-        static pwc::LdsAttrOnce once8;
-        if (const int rc = pwc::ensure_lds_attr(once8, reinterpret_cast<const void *>(&conv3x3_wino8_kernel<MT>), G::kSmemBytes,
-                                                "conv3x3_wino8_kernel"))
-            return rc;
-        hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups, (unsigned)ksplit), dim3(kThreads8), G::kSmemBytes, st,
-                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0,
-                           cps, part, (int64_t)B * Cout * H * W);
-        pwc::note_kernel("conv3x3_wino8_kernel", MT, G::kTG, 1, dil, 1, 0);
-        return pwc::check_launch("conv3x3_wino8_kernel");
-    }
-    if (part) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv3x3_wino_fwd: split-K needs the eight-wave kernel");
-    hipLaunchKernelGGL(conv3x3_wino_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups), dim3(kThreads), G::kSmemBytes, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0);
-    pwc::note_kernel("conv3x3_wino_kernel", MT, G::kTG, 1, dil, 1, 0);
-    return pwc::check_launch("conv3x3_wino_kernel");
+    static pwc::LdsAttrOnce once8;
+    if (const int rc = pwc::ensure_lds_attr(once8, reinterpret_cast<const void *>(&conv3x3_wino8_kernel<MT>), G::kSmemBytes,
+                                            "conv3x3_wino8_kernel"))
+        return rc;
+    hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups, (unsigned)ksplit), dim3(kThreads8), G::kSmemBytes, st,
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0,
+                       cps, part, (int64_t)B * Cout * H * W);
+    pwc::note_kernel("conv3x3_wino8_kernel", MT, G::kTG, 1, dil, 1, 0);
+    return pwc::check_launch("conv3x3_wino8_kernel");
 }
 
 // Launch shape of a layer run with ONE cout-tile width (the widest that divides CoutP), and its split-K plan: a launch that leaves
@@ -810,7 +524,7 @@ extern "C" int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *b
     const int nblk32 = CoutP / 32;
     // split-K for launches that would leave most CUs idle (needs the caller's workspace; without it the layer runs unsplit)
     const WinoPlan sp = wino_plan(B, Cin, H, W, Cout, dilation);
-    if (sp.ksplit > 1 && wino_waves() == 8 && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 3u) &&
+    if (sp.ksplit > 1 && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 3u) &&
         workspace_bytes >= (int64_t)sp.ksplit * B * Cout * plane * (int64_t)sizeof(float)) {
         float *part = static_cast<float *>(workspace);
         int rc;

@@ -117,14 +117,16 @@ int launch_warp(const void *x, const void *flo, void *out, int B, int C, int H, 
 //                d ix / d u = flow_scale * W / max(W-1,1)        (align_corners = 0)
 //                           = flow_scale * (W-1) / max(W-1,1)    (align_corners = 1).
 // The mask is a constant: the reference thresholds it in place (PWCNet.py:174-175), which cuts its graph.
-// largest |grad_out| as float bits (order-independent: max), into *out (zeroed before)
+// largest |grad_out| as float bits (order-independent: max), into *out (zeroed before).  The bit pattern of |v| orders like the
+// value for finite numbers and puts +inf (0x7f800000) and every NaN (> 0x7f800000) above them, so a non-finite gradient leaves
+// *out >= 0x7f800000: the fixed-point path cannot represent it and the kernels below switch to float atomics for that call
+// (Inf / NaN then propagate into grad_x exactly as in the float path and in torch's grid_sample backward).
+constexpr unsigned kNonFiniteBits = 0x7f800000u;
 __global__ void __launch_bounds__(256)
 absmax_kernel(const float *__restrict__ v, int64_t n, unsigned *out) {
     unsigned m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float a = fabsf(v[i]);
-        if (a == a && a < __builtin_huge_valf()) m = max(m, __float_as_uint(a));     // finite values only
-    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(fabsf(v[i])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
@@ -139,7 +141,7 @@ __device__ __forceinline__ float fixed_scale(unsigned mbits) {
 __global__ void __launch_bounds__(256)
 fixed_to_float_kernel(const long long *__restrict__ acc, const unsigned *__restrict__ mbits, float *__restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || *mbits >= kNonFiniteBits) return;            // non-finite grad_out: warp_bwd_kernel already wrote grad_x (float atomics)
     out[i] = (float)((double)acc[i] / (double)fixed_scale(*mbits));
 }
 
@@ -195,7 +197,11 @@ warp_bwd_kernel(const float *__restrict__ x, const float *__restrict__ flo, cons
     const int64_t gbase = (int64_t)b * C * plane;
     const float *gob = go + (int64_t)b * C * plane + pix;
     float fscale = 0.f;
-    if constexpr (FIXED) fscale = fixed_scale(*mbits);
+    bool fixed = FIXED;
+    if constexpr (FIXED) {
+        fixed = *mbits < kNonFiniteBits;                        // uniform over the grid
+        fscale = fixed_scale(*mbits);
+    }
     float dix = 0.f, diy = 0.f;
     for (int c = 0; c < C; ++c, xb += plane, gob += plane) {
         const float g = gob[0];
@@ -204,7 +210,7 @@ warp_bwd_kernel(const float *__restrict__ x, const float *__restrict__ flo, cons
         dix += g * (ay0 * (s01 - s00) + ay1 * (s11 - s10));
         diy += g * (ax0 * (s10 - s00) + ax1 * (s11 - s01));
         const int64_t cb = gbase + (int64_t)c * plane;
-        if constexpr (FIXED) {
+        if (fixed) {
             // round(g * w * 2^k) as int64: deterministic per contribution, associative in the sum
             unsigned long long *a = reinterpret_cast<unsigned long long *>(gacc) + cb;
             if (w00 != 0.f) atomicAdd(a + o00, (unsigned long long)__double2ll_rn((double)(g * w00) * (double)fscale));
@@ -252,11 +258,12 @@ extern "C" int pwc_warp_bwd(const void *x, const void *flo, const void *grad_out
         long long *acc = static_cast<long long *>(workspace);
         unsigned *mbits = reinterpret_cast<unsigned *>(acc + nel);
         hipError_t e = hipMemsetAsync(workspace, 0, (size_t)nel * 8 + 16, st);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_x, 0, (size_t)nel * sizeof(float), st);     // target of the non-finite fallback
         if (e != hipSuccess) { pwc::set_error("pwc_warp_bwd: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
         const int mblk = (int)((nel + 255) / 256 < 2048 ? (nel + 255) / 256 : 2048);
         hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)mblk), dim3(256), 0, st, gf, nel, mbits);
         hipLaunchKernelGGL(warp_bwd_kernel<true>, dim3((unsigned)nblk), dim3(kWarpThreads), 0, st, xf, ff, gf,
-                           static_cast<float *>(nullptr), acc, mbits, static_cast<float *>(grad_flo), C, H, W, npix,
+                           static_cast<float *>(grad_x), acc, mbits, static_cast<float *>(grad_flo), C, H, W, npix,
                            flow_scale, align_corners, mask_threshold);
         hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, acc, mbits,
                            static_cast<float *>(grad_x), nel);

@@ -147,6 +147,15 @@ class PwcPlan:
                     if self.wino and co >= 32:
                         need = max(need, ops.conv3x3_wino_workspace_bytes(B, cin, h, w, co))
                     cin += co if co != 2 else 0
+            # the context layers can split too (dilated: D*D lattices; at small batch / image sizes they fall into the split-K
+            # window) -- pwc_conv3x3_wino_preferred counts the split, so the workspace must be there for it
+            h, w = self.size[2]
+            cin = level_in_channels(2, self.nd) + DENSE_TOTAL
+            for co, dil in CONTEXT:
+                need = max(need, ops.conv3x3_workspace_bytes(B, cin, h, w, co, 1, dil))
+                if self.wino and dil <= 8:
+                    need = max(need, ops.conv3x3_wino_workspace_bytes(B, cin, h, w, co, dil))
+                cin = co
             if need:
                 self.workspace = torch.empty((need // 4,), **kw)
 

@@ -227,7 +227,7 @@ class _Ingest:
     image (numpy.copyto: 11 MB in 0.26 ms on the GPU box); Tensor.copy_ fans a 1.4 MB image out over every OpenMP thread
     torch sees (128 on a box whose share is 16) and took 2-3 ms for the same bytes, which capped the whole stream at
     ~1000 pairs/s while the captured pipeline does 2300-3400
-    (tools/host_pin_test.py, tools/bench_kitti_parts.py)."""
+    (tools/bench_host_pin.py, tools/bench_kitti_parts.py)."""
 
     def __init__(self, pairs, device: torch.device, batch: int):
         self.pairs, self.device, self.batch = iter(pairs), device, batch

@@ -34,7 +34,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import PwcHipError
-from .correlation import Correlation
+from .correlation import Correlation, onnx_correlation_enabled
 from .engine import (CONTEXT, DENSE_OUT, PYRAMID_CH, PYRAMID_NAMES, PYRAMID_NAMES_OLD, PwcPlan,
                      level_in_channels)
 from .weights import load_checkpoint, synthetic_state_dict
@@ -145,9 +145,16 @@ class PWCDCNet(nn.Module):
         return out.clone()
 
     # ---- plan management -----------------------------------------------------------------------
+    def _normalize_now(self) -> bool:
+        """The reference's net switches its correlation with the module global USE_ONNX_CORRELATION
+        (correlation.py:103-110: flag on -> the un-normalised torch expression, flag off -> the native operator).  The
+        forward honours the flag the same way: with it on, the cost volumes are un-normalised whatever
+        ``normalize_corr`` says (computed by the same HIP kernels -- the two expressions differ by the factor 1/C only)."""
+        return bool(self.normalize_corr) and not onnx_correlation_enabled()
+
     def _key(self, x):
         return (x.shape[0], x.shape[2], x.shape[3], x.dtype, x.device, self.conv_backend,
-                self.normalize_corr, self.align_corners, self.precision)
+                self._normalize_now(), self.align_corners, self.precision)
 
     def _param_versions(self):
         # in-place updates bump _version; re-homing (.to/.cuda/load_state_dict) goes through _apply /
@@ -184,10 +191,10 @@ class PWCDCNet(nn.Module):
                     raise NotImplementedError("precision='fp16' is built for conv_backend='hip' and float32 input")
                 from .engine_f16 import PwcPlanF16
                 plan = PwcPlanF16(params, x.shape[0], x.shape[2], x.shape[3], x.device, self.md,
-                                  self.normalize_corr, self.align_corners, self.variant)
+                                  self._normalize_now(), self.align_corners, self.variant)
             else:
                 plan = PwcPlan(params, x.shape[0], x.shape[2], x.shape[3], x.device, x.dtype, self.md,
-                               self.normalize_corr, self.align_corners, self.conv_backend, self.variant)
+                               self._normalize_now(), self.align_corners, self.conv_backend, self.variant)
             self._plans[key] = plan
             while len(self._plans) > max(1, int(self.max_cached_plans)):
                 old, _ = self._plans.popitem(last=False)

@@ -10,7 +10,7 @@ Recipe: two process-local shims, no reference file is edi
     CUDA extension at import time; it is never called because USE_ONNX_CORRELATION is set);
   * ``torch.Tensor.cuda`` = identity (reference PWCNet.py:167 calls .cuda() unconditionally).
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [old]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [old|wino]
 """
 import hashlib
 import os
@@ -151,6 +151,49 @@ def gen_forward():
     return net, manifest
 
 
+def gen_forward_wino():
+    """g7 (round 3): inputs large enough that the build's fp32 plan takes its Winograd / fused warp+correlation / split-K routes
+    (4x6x256x512: level 2 = 64x128 -> 256 workgroups per 128-cout launch) and the headline geometry 1x6x448x1024, so that the
+    REFERENCE's own outputs -- not only the oracle's -- pin the kernels that carry the benchmark step.  Same synthetic-weight
+    recipe as g3; inputs are regenerated from (shape, seed) by the tests and pinned by sha256."""
+    net = RefNet().eval()
+    manifest = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = synthetic_state_dict(manifest, seed=WSEED, gain=GAIN, bias_std=BIAS_STD)
+    net.load_state_dict(sd, strict=True)
+    cases = {"gain": np.array(GAIN), "bias_std": np.array(BIAS_STD), "wseed": np.array(WSEED)}
+    cases["weights_digest"] = np.array(hashlib.sha256(b"".join(sd[k].numpy().tobytes() for k, _ in manifest)).hexdigest())
+    torch.set_default_dtype(torch.float64)
+    try:
+        net64 = RefNet().double().eval()
+        net64.load_state_dict({k: v.double() for k, v in sd.items()})
+    finally:
+        torch.set_default_dtype(torch.float32)
+    for tag, shape, seed in (("w", (4, 6, 256, 512), 1236), ("full", (1, 6, 448, 1024), 1237)):
+        x = rand(shape, seed)
+        cases["xseed_" + tag] = np.array(seed)
+        cases["xshape_" + tag] = np.array(shape)
+        cases["xdigest_" + tag] = np.array(digest(x))
+        with torch.no_grad():
+            net.eval()
+            f2 = net(x)
+            net.train()
+            outs = net(x)
+            net.eval()
+            torch.set_default_dtype(torch.float64)
+            try:
+                f2d = net64(x.double())
+            finally:
+                torch.set_default_dtype(torch.float32)
+        cases["flow2_" + tag] = f2.numpy()
+        for lvl, o in zip((3, 4, 5, 6), outs[1:]):
+            cases["train_flow%d_%s" % (lvl, tag)] = o.numpy()
+        assert torch.equal(outs[0], f2)
+        cases["flow2_f64_" + tag] = f2d.numpy()
+        e = torch.sqrt(((f2.double() - f2d) ** 2).sum(1)).mean().item()
+        print("g7_forward_wino[%s]: mean|flow2| %.4f, fp32-vs-fp64 EPE %.3e" % (tag, f2.abs().mean().item(), e))
+    np.savez_compressed(os.path.join(OUT, "g7_forward_wino.npz"), **cases)
+
+
 def gen_manifest(manifest):
     # default-initialised reference network: per-tensor sums pin the init recipe (PWCNet.py:134-138)
     torch.manual_seed(0)
@@ -226,12 +269,16 @@ def main():
     if sys.argv[1:] == ["old"]:          # only the PWCDCNet_old fixture (leaves g1..g5 untouched)
         gen_old()
         return
+    if sys.argv[1:] == ["wino"]:         # only the large-geometry forward fixture (round 3)
+        gen_forward_wino()
+        return
     gen_corr()
     net, manifest = gen_forward()
     gen_warp(net)
     gen_manifest(manifest)
     gen_flo()
     gen_old()
+    gen_forward_wino()
 
 
 if __name__ == "__main__":

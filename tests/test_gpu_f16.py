@@ -294,6 +294,27 @@ def test_half_stores_saturate_no_inf_nan(dev):
     assert torch.isfinite(out).all()
 
 
+def test_half_stores_keep_nan(dev):
+    """the saturating half store must not launder NaN into -65504 (v_med3_f32 with a NaN operand returns the minimum of
+    the other two): a NaN in an activation or a filter stays NaN through conv3x3_f16, corr81_c8 and the level-entry kernel, so the
+    callers' isfinite checks (bench.py `outputs_finite`, the tests) can see it."""
+    from opticalflow_amd import ops_f16 as F16
+    x = seeded_rand((1, 16, 12, 40), 590, -1, 1)
+    x[0, 3, 5, 17] = float("nan")
+    w = seeded_rand((32, 16, 3, 3), 591, -0.2, 0.2)
+    y = F16.from_c8(F16.conv3x3_f16(F16.to_c8(x.to(dev)), F16.pack_conv3x3_f16(w.to(dev)), torch.zeros(32, device=dev), 16, 32), 32).cpu()
+    assert torch.isnan(y[0, :, 4:7, 16:19]).all() and torch.isfinite(y[0, :, :3]).all()
+    yf = F16.conv3x3_f16(F16.to_c8(x.to(dev)), F16.pack_conv3x3_f16(w.to(dev)), torch.zeros(32, device=dev), 16, 32, out_f32=True).cpu()
+    assert torch.isnan(yf[0, :, 5, 17, :]).all()
+    a = seeded_rand((1, 32, 16, 32), 592, -1, 1)
+    b = seeded_rand((1, 32, 16, 32), 593, -1, 1)
+    a[0, 7, 8, 9] = float("nan")
+    c = F16.from_c8(F16.correlation_c8(F16.to_c8(a.to(dev)), F16.to_c8(b.to(dev)), 32, leaky_slope=0.1), 81).cpu()
+    assert torch.isnan(c[0, :, 8, 9]).all() and torch.isfinite(c[0, :, 0, :4]).all()
+    wrp = F16.from_c8(F16.warp_c8(F16.to_c8(a.to(dev)), torch.zeros((1, 1, 16, 32, 8), device=dev, dtype=torch.float16), 32), 32).cpu()
+    assert torch.isnan(wrp[0, 7]).any() and not torch.isnan(wrp[0, :7]).any() and not torch.isnan(wrp[0, 8:]).any()
+
+
 # Bars of the half-precision plan (fp32 flow chain, split head filters; see DESIGN.md section 7 and
 # profiles/r02_f16_error_budget.txt): the network stores ~25 tensors per level in half (11-bit significands), which
 # alone puts the flow ~1e-3 RELATIVE from the fp32 result -- a CPU emulation with nothing but those roundings gives

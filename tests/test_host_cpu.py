@@ -3,6 +3,7 @@ No compute call is made (there is no GPU here); kernels are exercised by tests/t
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -193,11 +194,50 @@ def test_drop_in_import_paths():
     import opticalflow_amd.correlation as impl
     a = torch.randn(1, 6, 10, 12, generator=torch.Generator().manual_seed(3))
     b = torch.randn(1, 6, 10, 12, generator=torch.Generator().manual_seed(4))
-    impl.USE_ONNX_CORRELATION = True                   # reference fallback (correlation.py:103-110): un-normalised, any device
+    # the reference's callers set the flag on the module they import under THIS path (pth2onnx.py:44-46,
+    # onnx_pth_compare.py:91-93): `corr_mod.USE_ONNX_CORRELATION = True`
+    import models.correlation_package.correlation as corr_mod
+    assert corr_mod.USE_ONNX_CORRELATION is False and impl.onnx_correlation_enabled() is False
+    corr_mod.USE_ONNX_CORRELATION = True               # reference fallback (correlation.py:103-110): un-normalised, any device
+    try:
+        assert impl.onnx_correlation_enabled() is True
+        assert torch.allclose(m(a, b), O.correlation(a, b, 4, 1, 4, 1, 1, 1), atol=1e-5)
+        # the implementation module's own Correlation follows the same switch (CPU tensors: only the traceable expression can run)
+        assert torch.allclose(impl.Correlation(4, 1, 4, 1, 1)(a, b), O.correlation(a, b, 4, 1, 4, 1, 1, 1), atol=1e-5)
+        # ... and so does the net: its plans are keyed on the EFFECTIVE normalisation (PWCDCNet._normalize_now)
+        from models.PWCNet import PWCDCNet as ShimNet
+        net = ShimNet()
+        assert net.normalize_corr is True and net._normalize_now() is False
+    finally:
+        corr_mod.USE_ONNX_CORRELATION = False
+    assert net._normalize_now() is True
+    with pytest.raises(Exception):                     # flag off: the native operator, which has no CPU path
+        m(a, b)
+    impl.USE_ONNX_CORRELATION = True                   # setting it on the implementation module works as well
     try:
         assert torch.allclose(m(a, b), O.correlation(a, b, 4, 1, 4, 1, 1, 1), atol=1e-5)
     finally:
         impl.USE_ONNX_CORRELATION = False
+
+
+def test_models_pwcnet_classes_default_to_native_correlation():
+    """ADVICE r2: the reference's scripts build the net as `from models.PWCNet import PWCDCNet; PWCDCNet();
+    load_state_dict(ckpt)` (inference_kitti.py:301, inference.py:328, pwc_extract_flow.py:129): the classes exported under
+    the reference's import path mirror the reference's module, whose correlation is the native one (/C); the package's
+    own classes keep the parity default."""
+    from models.PWCNet import PWCDCNet, PWCDCNet_old
+    import models
+    import opticalflow_amd as pkg
+    from opticalflow_amd.weights import synthetic_state_dict
+    for cls, base in ((PWCDCNet, pkg.pwcnet.PWCDCNet), (PWCDCNet_old, pkg.pwcnet.PWCDCNet_old)):
+        net = cls()
+        assert isinstance(net, base) and net.normalize_corr is True and net.corr.normalize is True
+        net.load_state_dict(synthetic_state_dict(net.manifest(), seed=2), strict=True)
+        assert cls(normalize_corr=False).normalize_corr is False           # still selectable
+        assert base().normalize_corr is False
+    assert models.pwc_dc_net().normalize_corr is True and type(models.pwc_dc_net()) is PWCDCNet
+    assert models.pwc_dc_net_old().normalize_corr is True
+    assert [k for k, _ in PWCDCNet().manifest()] == [k for k, _ in pkg.PWCDCNet().manifest()]
 
 
 def test_checkpoint_factories_default_to_native_correlation(tmp_path):
@@ -251,3 +291,35 @@ def test_old_variant_state_dict_and_channel_permutation():
     got = torch.nn.functional.conv2d(torch.cat([xs["c2"], xs["c1"], xs["c0"], xs["base"]], 1),
                                      w.index_select(1, old_variant_perm(3, od)), padding=1)
     assert (ref - got).abs().max().item() < 1e-3
+
+
+def test_bench_self_launches_its_ranks(monkeypatch):
+    """VERDICT r2 missing #2: `python bench.py --gpus N` (no WORLD_SIZE) starts torch.distributed.run as a CHILD process with the
+    driver's flags and the same arguments, and exits with the child's code; under torch.distributed.run it does not re-launch."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "kitti"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "kitti"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    # a rank whose WORLD_SIZE disagrees with --gpus is an error, not a second launch
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    seen.clear()
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert not seen and "WORLD_SIZE=2" in str(ei.value.code)

@@ -87,6 +87,26 @@ def test_g3_forward_matches_reference():
         assert O.epe(outs[0], torch.from_numpy(g["flow2_f64_" + tag])) < 1e-4
 
 
+def test_g7_large_forward_matches_reference():
+    """g7 (round 3): the reference's own outputs at 4x6x256x512 and at the headline geometry 1x6x448x1024 -- the sizes at which
+    the build's plan takes its Winograd / fused / split-K routes -- pin the oracle there too."""
+    g = load_golden("g7_forward_wino.npz")
+    sd = synthetic_state_dict(O.state_dict_manifest(), seed=int(g["wseed"]), gain=float(g["gain"]),
+                              bias_std=float(g["bias_std"]))
+    blob = b"".join(sd[k].numpy().tobytes() for k, _ in O.state_dict_manifest())
+    assert hashlib.sha256(blob).hexdigest() == str(g["weights_digest"]), "weight recipe drifted"
+    torch.set_num_threads(8)
+    for tag in ("w", "full"):
+        x = seeded_rand(g["xshape_" + tag], g["xseed_" + tag])
+        assert _digest(x) == str(g["xdigest_" + tag])
+        with torch.no_grad():
+            outs = O.pwc_forward(sd, x, all_levels=True)
+        assert O.epe(outs[0], torch.from_numpy(g["flow2_" + tag])) < 1e-5
+        for lvl, o in zip((3, 4, 5, 6), outs[1:]):
+            assert O.epe(o, torch.from_numpy(g["train_flow%d_%s" % (lvl, tag)])) < 1e-5, (tag, lvl)
+        assert O.epe(outs[0], torch.from_numpy(g["flow2_f64_" + tag])) < 1e-4
+
+
 def test_g6_old_variant_matches_reference():
     """PWCDCNet_old (PWCNet.py:277-491) restatement vs the reference's own output."""
     g = load_golden("g6_old.npz")
