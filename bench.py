@@ -360,7 +360,7 @@ def main():
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--conv-backend", default="hip", choices=["hip", "torch"])
-    ap.add_argument("--precision", default=None, choices=["fp32", "fp16"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "fp16", "fp16-strict"],
                     help="fp32 = the headline metric (BASELINE configs[2]); fp16 = half activations/filters, fp32 accumulation (configs[3])")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -464,7 +464,8 @@ def main():
             "config": {"workload": ("BASELINE configs[2]: batch=%d/GPU %dx%d fp32, full HIP path (corr+warp+MFMA convs)%s"
                                     % (B, W, H, "" if args.conv_backend == "hip" else " [convs on PyTorch-ROCm: configs[1]]")) if fp32 else
                                    ("BASELINE configs[3] per-GPU shard: batch=%d/GPU %dx%d, fp16 activations and filters (c8 layout), "
-                                    "fp32 accumulation, fp32 input/output" % (B, W, H)),
+                                    "fp32 accumulation, fp32 input/output%s" % (B, W, H, "" if args.precision == "fp16" else
+                                                                                 " [strict mode: fp32 pyramid / levels 6-3 / warps, split filters]")),
                        "pairs_per_gpu": B, "global_batch": B * world, "height": H, "width": W,
                        "conv_backend": args.conv_backend, "hip_graph": not args.no_graph,
                        "parallelism": "batch-shard x%d, weights broadcast %d B, flow gather to rank 0" % (world, bcast_bytes)},
@@ -489,6 +490,15 @@ def main():
         h2, w2 = H >> 2, W >> 2
         if fp32:
             probes_fp32(result, args, plan, B, H, W, h2, w2, stream)
+        elif args.precision == "fp16-strict":
+            # dominant kernel of the strict mode: dc_conv1 in half with split filters = twice the MFMA passes of the plain layer
+            flops = 2.0 * 2 * 128 * 565 * 9 * h2 * w2 * B
+            ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena, plan.ctx[0], dilation=1), PROBE_REPS, stream)
+            ach = flops / (ms * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "%s (dc_conv1 565->128 @%dx%d, B=%d, split hi+lo filters: 256 MFMA rows)" % (last_conv_kernel(), w2, h2, B),
+                                  "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+                                  "launches_timed": PROBE_REPS, "algorithmic_flop_per_launch": flops}
         else:
             probes_fp16(result, plan, B, H, W, h2, w2, stream)
 
@@ -523,6 +533,26 @@ def main():
                 "epe_vs_fp32_plan": float("%.3e" % O.epe(out16.cpu(), f32out.cpu())),
                 "mean_abs_flow": float("%.3e" % f32out.abs().mean().item())}
             del net16
+            # ... and through the STRICT half-precision mode (pyramid / levels 6..3 / warps in fp32, level 2 + context network in half
+            # with split filters): the variant that meets north_star's 1e-3 mean EPE
+            log("side measurement: same workload, precision=fp16-strict")
+            nets = PWCDCNet(use_graph=True, precision="fp16-strict").to(dev).eval()
+            nets.load_state_dict(net.state_dict())
+            xs_ = nets.graph_input(B, H, W, dev)
+            xs_.copy_(x)
+            for _ in range(3):
+                nets(xs_)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                outs_ = nets(xs_)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+            result["fp16_strict_same_workload"] = {
+                "value": round(B * args.steps / dts, 3), "unit": "image-pairs/s", "ms_per_step": round(1e3 * dts / args.steps, 4),
+                "dtype": "f32 pyramid / levels 6-3 / warps; f16 activations with split (hi+lo) filters at level 2 and in the context network",
+                "epe_vs_fp32_plan": float("%.3e" % O.epe(outs_.cpu(), f32out.cpu()))}
+            del nets
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
             torch.set_num_threads(cores)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 7
+#define PWC_ABI_VERSION 8
 
 /* element types */
 #define PWC_F32 0
@@ -55,8 +55,9 @@ extern "C" {
 /* pwc_conv2d_f16_fwd only */
 #define PWC_CONV_OUT_F32 8u   /* y is float [B][ceil(Cout/8)][Ho][Wo][8] instead of half (flow heads: the values that
                                  carry the flow from level to level stay in fp32)                    */
-#define PWC_CONV_SPLIT_W 16u  /* wp comes from pwc_conv3x3_f16_pack_split (Cout <= 16): ~22-bit filters at no extra
-                                 MFMA cost, for the 2-channel heads                                  */
+#define PWC_CONV_SPLIT_W 16u  /* wp comes from pwc_conv3x3_f16_pack_split: hi + lo filters (~22 bits).  Free for Cout <= 16 (the
+                                 2-channel heads: the residuals ride in the idle half of the 32-row cout tile); twice the
+                                 MFMA passes otherwise (the strict half-precision mode's level-2 / context layers)        */
 
 int pwc_abi_version(void);
 const char *pwc_last_error(void);
@@ -176,8 +177,10 @@ int64_t pwc_conv3x3_wino_workspace_bytes(int B, int Cin, int H, int W, int Cout,
 int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout);
 /* w: [Cout,Cin,3,3] f32 (nn.Conv2d layout, device) -> wp: packed halves [Cg/2][tap][2][CoutP][8]. */
 int pwc_conv3x3_f16_pack(const void *w, void *wp, int Cin, int Cout, void *stream);
-/* Same size and layout for Cout <= 16 with the 16 unused rows of the 32-row cout tile carrying the rounding residual
- * of each filter (times 2^11): y = sum(hi) + sum(lo)/2^11 in the epilogue of pwc_conv2d_f16_fwd(PWC_CONV_SPLIT_W). */
+/* Split filters: the same layout with CoutP = 32 * ceil(Cout / 16) -- every 32-row cout tile carries 16 filters rounded to half
+ * (rows 0..15) and their rounding residuals times 2^11 (rows 16..31): y = sum(hi) + sum(lo)/2^11 in the epilogue of
+ * pwc_conv2d_f16_fwd(PWC_CONV_SPLIT_W).  pwc_conv3x3_f16_packed_bytes_split bytes (= the plain size for Cout <= 16). */
+int64_t pwc_conv3x3_f16_packed_bytes_split(int Cin, int Cout);
 int pwc_conv3x3_f16_pack_split(const void *w, void *wp, int Cin, int Cout, void *stream);
 int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
                        int B, int Cin, int H, int W, int Cout, int stride, int dilation,

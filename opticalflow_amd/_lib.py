@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
 LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
@@ -45,6 +45,7 @@ SIGNATURES = {
                                c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "pwc_conv2d_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "pwc_conv3x3_f16_packed_bytes": (c_int64, [c_int, c_int]),
+    "pwc_conv3x3_f16_packed_bytes_split": (c_int64, [c_int, c_int]),
     "pwc_conv3x3_f16_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pwc_conv3x3_f16_pack_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pwc_conv3x3_wino_packed_bytes": (c_int64, [c_int, c_int]),

@@ -142,9 +142,12 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+            // split filters: every 32-row block carries 16 couts -- rows 0..15 the filters rounded to half, rows 16..31 their
+            // rounding residuals (no bias there)
+            const int co = split_w ? (g * G::kCoutT + mt * 32) / 2 + (j & 3) + 8 * ((j >> 2) & 1) + 4 * kh
+                                   : g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
             float bv = bias[min(co, Cout - 1)];
-            if (split_w && j >= 8) bv = 0.f;              // rows 16..31 carry the low halves of the filters: no bias
+            if (split_w && j >= 8) bv = 0.f;
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) acc[mt][nt][j] = bv;
         }
@@ -185,13 +188,14 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cg = (g * G::kCoutT + mt * 32) / 8 + q;
+                if (split_w && q >= 2) continue;                       // 16 couts = 2 output groups per 32-row block
+                const int cg = split_w ? (g * G::kCoutT + mt * 32) / 16 + q : (g * G::kCoutT + mt * 32) / 8 + q;
                 if (cg >= cg_out) continue;
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     v[i] = acc[mt][nt][4 * q + i];
-                    // split filters (Cout <= 16): row co + 16 = sum over the low halves scaled by 2^11 (q < 2 always here)
+                    // split filters: row r + 16 = the sum over the filters' low halves scaled by 2^11 (same lane, register + 8)
                     if (split_w) v[i] += acc[mt][nt][(4 * q + i + 8) & 15] * (1.0f / 2048.0f);
                     if (do_leaky) v[i] = pwc::leaky(v[i], slope);
                     if (cg * 8 + 4 * kh + i >= Cout) v[i] = 0.f;
@@ -297,7 +301,7 @@ conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict_
         }
     };
 
-    const bool do_leaky = mode & kModeLeaky, out_f32 = mode & kModeOutF32;
+    const bool do_leaky = mode & kModeLeaky, out_f32 = mode & kModeOutF32, split_w = mode & kModeSplitW;
     const int64_t oplane = (int64_t)H * W;
     const int cg_out = (Cout + 7) / 8;
 
@@ -309,8 +313,9 @@ conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict_
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int co = g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
-                const float bv = bias[min(co, Cout - 1)];
+                const int co = split_w ? (g * G::kCoutT + mt * 32) / 2 + (j & 3) + 8 * ((j >> 2) & 1) + 4 * kh
+                                       : g * G::kCoutT + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh;
+                const float bv = (split_w && j >= 8) ? 0.f : bias[min(co, Cout - 1)];     // split filters: see conv3x3_f16_kernel
                 acc[mt][0][j] = bv;
                 acc[mt][1][j] = bv;
             }
@@ -350,12 +355,14 @@ conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict_
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int cg = (g * G::kCoutT + mt * 32) / 8 + q;
+                    if (split_w && q >= 2) continue;
+                    const int cg = split_w ? (g * G::kCoutT + mt * 32) / 16 + q : (g * G::kCoutT + mt * 32) / 8 + q;
                     if (cg >= cg_out) continue;
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         v[i] = acc[mt][nt][4 * q + i];
+                        if (split_w) v[i] += acc[mt][nt][(4 * q + i + 8) & 15] * (1.0f / 2048.0f);
                         if (do_leaky) v[i] = pwc::leaky(v[i], slope);
                         if (cg * 8 + 4 * kh + i >= Cout) v[i] = 0.f;
                     }
@@ -375,8 +382,9 @@ conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict_
 }
 
 // wp[cgp][tap][kh][CoutP][8] <- w[co][ci = 8*(2*cgp + kh) + j][tap]   (zero outside Cin / Cout)
-// split = 1 (Cout <= 16, CoutP = 32): row co holds the filter rounded to half, row co + 16 the rounding residual
-// times 2^11 (exact scaling; keeps it out of the subnormal range), so that hi + lo / 2^11 carries ~22 bits of the filter
+// split = 1 (CoutP = 32 * ceil(Cout / 16)): every 32-row block carries 16 couts -- row r < 16 holds filter 16*block + r rounded
+// to half, row r + 16 its rounding residual times 2^11 (exact scaling; keeps it out of the subnormal range), so that
+// hi + lo / 2^11 carries ~22 bits of the filter; the two partial sums of a cout sit in the same lane of the MFMA tile
 __global__ void __launch_bounds__(256)
 pack3x3_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int Cin, int Cout, int CoutP, int64_t total, int split) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,10 +399,10 @@ pack3x3_f16_kernel(const float *__restrict__ w, _Float16 *__restrict__ wp, int C
     const int cgp = (int)(t / 9);
     const int ci = 8 * (2 * cgp + kh) + j;
     float v = 0.f;
-    const int cs = split ? (co & 15) : co;
+    const int cs = split ? (co >> 5) * 16 + (co & 15) : co;
     if (cs < Cout && ci < Cin) v = w[((int64_t)cs * Cin + ci) * 9 + tap];
     const _Float16 hi = pwc::sat_half(v);
-    wp[i] = (split && co >= 16) ? (_Float16)((v - (float)hi) * 2048.0f) : hi;
+    wp[i] = (split && (co & 16)) ? (_Float16)((v - (float)hi) * 2048.0f) : hi;
 }
 
 // [B][C][H][W] f32 -> [B][Cg][H][W][8] f16 (zero channel padding) and back
@@ -519,7 +527,7 @@ int dispatch16(const Args16 &a) {
         const char *e = getenv("PWC_CONV16F_W8");
         const int w8 = (e && *e) ? atoi(e) : -1;
         const int64_t tiles16w = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 15) / 16);
-        if (w8 != 0 && !(a.mode & kModeSplitW) && tiles16w >= 256) {
+        if (w8 != 0 && !((a.mode & kModeSplitW) && a.Cout <= 16) && tiles16w >= 256) {
             int mt = 0;
             if (w8 > 0) {
                 mt = min(w8, t32 == 3 ? 3 : t32);
@@ -537,7 +545,7 @@ int dispatch16(const Args16 &a) {
         }
     }
     int want = forced_mt > 0 ? min(forced_mt, t32) : min(t32, 4);
-    if (a.mode & kModeSplitW) want = 1;
+    if ((a.mode & kModeSplitW) && a.Cout <= 16) want = 1;
     // small grids (levels 6-4, batch-1 inference): narrower cout tiles = more workgroups; a workgroup's K loop is then
     // bound by its DMA round trips instead of MT x as many MFMAs, and the tiny input is simply re-read per cout group
     const int64_t tiles8 = (int64_t)a.B * ((a.Wo + kTileW - 1) / kTileW) * ((a.Ho + 7) / 8);
@@ -579,6 +587,7 @@ int dispatch16(const Args16 &a) {
 }
 
 inline int cout_padded(int Cout) { return (Cout + 31) / 32 * 32; }
+inline int cout_padded_split(int Cout) { return (Cout + 15) / 16 * 32; }      // 16 couts (hi + lo rows) per 32-row block
 
 }  // namespace
 
@@ -588,14 +597,20 @@ extern "C" int64_t pwc_conv3x3_f16_packed_bytes(int Cin, int Cout) {
     return (int64_t)((cg + 1) / 2) * 18 * cout_padded(Cout) * 16;
 }
 
+extern "C" int64_t pwc_conv3x3_f16_packed_bytes_split(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return -1;
+    const int cg = (Cin + 7) / 8;
+    return (int64_t)((cg + 1) / 2) * 18 * cout_padded_split(Cout) * 16;
+}
+
 static int pack_f16(const void *w, void *wp, int Cin, int Cout, void *stream, int split, const char *who) {
     if (!w || !wp) PWC_FAIL(PWC_EINVAL, "%s: null pointer", who);
     if (Cin <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "%s: bad shape", who);
-    if (split && Cout > 16) PWC_FAIL(PWC_EUNSUPPORTED, "%s: split filters need Cout <= 16 (got %d)", who, Cout);
     if (!pwc::aligned16(wp)) PWC_FAIL(PWC_EALIGN, "%s: packed buffer must be 16-byte aligned", who);
-    const int64_t total = pwc_conv3x3_f16_packed_bytes(Cin, Cout) / 2;
+    const int64_t total = (split ? pwc_conv3x3_f16_packed_bytes_split(Cin, Cout) : pwc_conv3x3_f16_packed_bytes(Cin, Cout)) / 2;
     hipLaunchKernelGGL(pack3x3_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float *>(w), static_cast<_Float16 *>(wp), Cin, Cout, cout_padded(Cout), total, split);
+                       static_cast<const float *>(w), static_cast<_Float16 *>(wp), Cin, Cout,
+                       split ? cout_padded_split(Cout) : cout_padded(Cout), total, split);
     return pwc::check_launch("pack3x3_f16_kernel");
 }
 
@@ -637,7 +652,6 @@ extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bia
     if (!pwc::aligned16(x) || !pwc::aligned16(y) || !pwc::aligned16(wp) || (x_bstride % 8) || (y_bstride % 8))
         PWC_FAIL(PWC_EALIGN, "pwc_conv2d_f16_fwd: tensors must be 16-byte aligned with batch strides that are multiples of 8");
     if (flags & PWC_CONV_RESIDUAL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: residual is not implemented for fp16");
-    if ((flags & PWC_CONV_SPLIT_W) && Cout > 16) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv2d_f16_fwd: split filters need Cout <= 16 (got %d)", Cout);
     const int64_t plane = (int64_t)H * W;
     const int cg = (Cin + 7) / 8;
     if (x_bstride < (int64_t)cg * plane * 8) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: x batch stride < Cg*H*W*8");
@@ -647,7 +661,8 @@ extern "C" int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bia
     a.wp = static_cast<const _Float16 *>(wp);
     a.bias = static_cast<const float *>(bias);
     a.y = y;
-    a.B = B; a.Cg = cg; a.H = H; a.W = W; a.Cout = Cout; a.CoutP = cout_padded(Cout);
+    a.B = B; a.Cg = cg; a.H = H; a.W = W; a.Cout = Cout;
+    a.CoutP = (flags & PWC_CONV_SPLIT_W) ? cout_padded_split(Cout) : cout_padded(Cout);
     a.Ho = (H - 1) / stride + 1;
     a.Wo = (W - 1) / stride + 1;
     a.bsx = x_bstride; a.bsy = y_bstride;

@@ -68,12 +68,16 @@ def level_in_channels(level: int, nd: int = 81) -> int:
 class PwcPlan:
     def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device,
                  dtype: torch.dtype = torch.float32, md: int = 4, normalize_corr: bool = False,
-                 align_corners: bool = False, conv_backend: str = "hip", variant: str = "dc"):
+                 align_corners: bool = False, conv_backend: str = "hip", variant: str = "dc", trunk2: bool = True):
+        """trunk2=False (engine_strict.PwcPlanStrict): this plan stops after the level-2 ENTRY (correlation, c1, up_flow, up_feat);
+        the level-2 dense block, flow head and context network belong to the caller, so their buffers and packed filters are not
+        allocated and the level-2 arena holds only its 117 base channels."""
         if variant not in ("dc", "old"):
             raise ValueError("variant must be 'dc' (PWCDCNet) or 'old' (PWCDCNet_old)")
         if H % 64 or W % 64 or H <= 0 or W <= 0:
             raise ValueError("PWCDCNet needs H and W to be positive multiples of 64 (got %dx%d); resize or pad the "
                              "pair first like script_pwc.py:47-54 / inference_kitti.py:53-63" % (H, W))
+        self.trunk2 = trunk2
         if conv_backend not in ("hip", "torch"):
             raise ValueError("conv_backend must be 'hip' or 'torch'")
         if dtype != torch.float32:
@@ -117,13 +121,15 @@ class PwcPlan:
             self.c1[l], self.c2[l] = self._pair_views(self.pyr_a[l], B)
         self.warped = {l: torch.empty((B, PYRAMID_CH[l], *self.size[l]), **kw) for l in range(2, 6)}
         self.arena = {}
+        self.arena_base = {}                    # first channel after the dense-block outputs
         for l in range(2, 7):
             od = level_in_channels(l, self.nd)
-            self.arena[l] = torch.empty((B, DENSE_TOTAL + od, *self.size[l]), **kw)
-        self.flow = {l: torch.empty((B, 2, *self.size[l]), **kw) for l in range(2, 7)}
-        self.flow_out = torch.empty((B, 2, *self.size[2]), **kw)
+            self.arena_base[l] = DENSE_TOTAL if (l > 2 or trunk2) else 0
+            self.arena[l] = torch.empty((B, self.arena_base[l] + od, *self.size[l]), **kw)
+        self.flow = {l: torch.empty((B, 2, *self.size[l]), **kw) for l in range(2 if trunk2 else 3, 7)}
         h2, w2 = self.size[2]
-        self.ctx = [torch.empty((B, c, h2, w2), **kw) for c, _ in CONTEXT]
+        self.flow_out = torch.empty((B, 2, h2, w2), **kw) if trunk2 else None
+        self.ctx = [torch.empty((B, c, h2, w2), **kw) for c, _ in CONTEXT] if trunk2 else []
 
         self.packed: Dict[str, torch.Tensor] = {}
         self.wino_packed: Dict[str, torch.Tensor] = {}
@@ -132,6 +138,8 @@ class PwcPlan:
         self.workspace: Optional[torch.Tensor] = None
         if conv_backend == "hip":
             for key, t in self.p.items():
+                if not trunk2 and key.startswith(("conv2_", "predict_flow2", "dc_conv")):
+                    continue                                   # run by the caller (engine_strict) in its own format
                 if key.endswith(".weight") and t.dim() == 4 and t.shape[2:] == (3, 3):
                     self.packed[key[:-len(".weight")]] = ops.pack_conv3x3(t)
                     # G g Gt for every layer the Winograd route could take (67 MB for the whole net): nothing is allocated later
@@ -139,7 +147,7 @@ class PwcPlan:
                         self.wino_packed[key[:-len(".weight")]] = ops.pack_conv3x3_wino(t)
             # one split-K scratch shared by every stride-1 conv of the decoder (they run back to back on one stream)
             need = 0
-            for l in range(2, 7):
+            for l in range(2 if trunk2 else 3, 7):
                 h, w = self.size[l]
                 cin = level_in_channels(l, self.nd)
                 for co in DENSE_OUT + (2,):
@@ -151,7 +159,7 @@ class PwcPlan:
             # window) -- pwc_conv3x3_wino_preferred counts the split, so the workspace must be there for it
             h, w = self.size[2]
             cin = level_in_channels(2, self.nd) + DENSE_TOTAL
-            for co, dil in CONTEXT:
+            for co, dil in (CONTEXT if trunk2 else ()):
                 need = max(need, ops.conv3x3_workspace_bytes(B, cin, h, w, co, 1, dil))
                 if self.wino and dil <= 8:
                     need = max(need, ops.conv3x3_wino_workspace_bytes(B, cin, h, w, co, dil))
@@ -235,54 +243,72 @@ class PwcPlan:
 
     def _decode(self) -> torch.Tensor:
         """Coarse-to-fine decoder + context network over self.c1[l] / self.c2[l] (PWCNet.py:198-268)."""
-        nd = self.nd
-        base = DENSE_TOTAL                      # first channel after the dense-block outputs
         for l in (6, 5, 4, 3, 2):
-            ar = self.arena[l]
-            c = PYRAMID_CH[l]
-            corr_slot = ar[:, base:base + nd]
-            if l == 6:
-                ops.correlation(self.c1[6], self.c2[6], self.md, 1, self.md, 1, 1, 1.0,
-                                normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
-            else:
-                off = base + nd
-                # first image's level features go into the level's arena slot (they are part of the
-                # dense block's input, PWCNet.py:215); c2 is only ever read by the warp
-                ar[:, off:off + c].copy_(self.c1[l])
-                up_flow = ar[:, off + c:off + c + 2]
-                # warp + correlation + LeakyReLU as one kernel (the warped features live in LDS only) where the geometry
-                # allows it (md = 4, W % 4 == 0); otherwise the two operators
-                fused = None
-                if self.fuse_warp and self.md == 4:
-                    fused = ops.warp_correlation(ar[:, off:off + c], self.c2[l], up_flow, flow_scale=WARP_SCALE[l],
-                                                 align_corners=self.align_corners, mask_threshold=self.mask_threshold,
-                                                 normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
-                if fused is None:
-                    ops.warp(self.c2[l], up_flow, flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
-                             mask_threshold=self.mask_threshold, out=self.warped[l])
-                    ops.correlation(ar[:, off:off + c], self.warped[l], self.md, 1, self.md, 1, 1, 1.0,
-                                    normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
-            lo = base
-            for i, (co, off_i) in enumerate(zip(DENSE_OUT, DENSE_OFF)):
-                self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, off_i:off_i + co])
-                lo = off_i
-            if l == 2:
-                self._conv("predict_flow2", ar, self.flow[2], act=False)
-            else:
-                nxt = self.arena[l - 1]
-                cn = PYRAMID_CH[l - 1]
-                o = base + nd + cn
-                h, w = self.size[l]
-                if self.conv_backend == "hip" and ops.head_upfeat_supported(self.B, h, w):
-                    # predict_flowL and upfeatL read the same 3x3 windows of the same arena: one pass
-                    ops.head_upfeat(ar, self.packed["predict_flow%d" % l], self.p["predict_flow%d.bias" % l],
-                                    self.p["upfeat%d.weight" % l], self.p["upfeat%d.bias" % l],
-                                    self.flow[l], nxt[:, o + 2:o + 4])
-                else:
-                    self._conv("predict_flow%d" % l, ar, self.flow[l], act=False)
-                    self._deconv("upfeat%d" % l, ar, nxt[:, o + 2:o + 4])
-                self._deconv("deconv%d" % l, self.flow[l], nxt[:, o:o + 2])
-        # -- context network (PWCNet.py:267-268) ------------------------------------------------------
+            self._level_entry(l)
+            self._dense(l)
+            self._heads(l)
+        return self._context()
+
+    def _level_entry(self, l: int) -> None:
+        """Cost volume of level l into its arena slot (PWCNet.py:198-199, 212-214 ...): plain correlation at level 6; below, c1
+        into its slot and warp(c2, up_flow * scale) + correlation + LeakyReLU as one kernel."""
+        nd, base = self.nd, self.arena_base[l]
+        ar = self.arena[l]
+        c = PYRAMID_CH[l]
+        corr_slot = ar[:, base:base + nd]
+        if l == 6:
+            ops.correlation(self.c1[6], self.c2[6], self.md, 1, self.md, 1, 1, 1.0,
+                            normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+            return
+        off = base + nd
+        # first image's level features go into the level's arena slot (they are part of the
+        # dense block's input, PWCNet.py:215); c2 is only ever read by the warp
+        ar[:, off:off + c].copy_(self.c1[l])
+        up_flow = ar[:, off + c:off + c + 2]
+        # warp + correlation + LeakyReLU as one kernel (the warped features live in LDS only) where the geometry
+        # allows it (md = 4, W % 4 == 0); otherwise the two operators
+        fused = None
+        if self.fuse_warp and self.md == 4:
+            fused = ops.warp_correlation(ar[:, off:off + c], self.c2[l], up_flow, flow_scale=WARP_SCALE[l],
+                                         align_corners=self.align_corners, mask_threshold=self.mask_threshold,
+                                         normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+        if fused is None:
+            ops.warp(self.c2[l], up_flow, flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
+                     mask_threshold=self.mask_threshold, out=self.warped[l])
+            ops.correlation(ar[:, off:off + c], self.warped[l], self.md, 1, self.md, 1, 1, 1.0,
+                            normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
+
+    def _dense(self, l: int) -> None:
+        """DenseNet block convL_0..convL_4 (PWCNet.py:202-206 ...): each layer reads a channel suffix of the arena and writes
+        its slice in front of it."""
+        ar = self.arena[l]
+        lo = self.arena_base[l]
+        for i, (co, off_i) in enumerate(zip(DENSE_OUT, DENSE_OFF)):
+            self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, off_i:off_i + co])
+            lo = off_i
+
+    def _heads(self, l: int) -> None:
+        """predict_flowL, and for l > 2 deconvL / upfeatL into the next level's arena (PWCNet.py:207-209 ...)."""
+        ar = self.arena[l]
+        if l == 2:
+            self._conv("predict_flow2", ar, self.flow[2], act=False)
+            return
+        nxt = self.arena[l - 1]
+        cn = PYRAMID_CH[l - 1]
+        o = self.arena_base[l - 1] + self.nd + cn
+        h, w = self.size[l]
+        if self.conv_backend == "hip" and ops.head_upfeat_supported(self.B, h, w):
+            # predict_flowL and upfeatL read the same 3x3 windows of the same arena: one pass
+            ops.head_upfeat(ar, self.packed["predict_flow%d" % l], self.p["predict_flow%d.bias" % l],
+                            self.p["upfeat%d.weight" % l], self.p["upfeat%d.bias" % l],
+                            self.flow[l], nxt[:, o + 2:o + 4])
+        else:
+            self._conv("predict_flow%d" % l, ar, self.flow[l], act=False)
+            self._deconv("upfeat%d" % l, ar, nxt[:, o + 2:o + 4])
+        self._deconv("deconv%d" % l, self.flow[l], nxt[:, o:o + 2])
+
+    def _context(self) -> torch.Tensor:
+        """Context network + residual (PWCNet.py:267-268)."""
         t = self.arena[2]
         for i, (_, dil) in enumerate(CONTEXT):
             self._conv("dc_conv%d" % (i + 1), t, self.ctx[i], dilation=dil)
@@ -298,7 +324,7 @@ class PwcPlan:
         tot = 0
         for group in (self.pyr_a, self.pyr_b, self.warped, self.arena, self.flow):
             tot += sum(t.numel() * t.element_size() for t in group.values())
-        tot += sum(t.numel() * t.element_size() for t in self.ctx + [self.flow_out])
+        tot += sum(t.numel() * t.element_size() for t in self.ctx + ([self.flow_out] if self.flow_out is not None else []))
         tot += sum(t.numel() * t.element_size() for t in self.packed.values())
         tot += sum(t.numel() * t.element_size() for t in self.wino_packed.values())
         if self.workspace is not None:

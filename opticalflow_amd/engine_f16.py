@@ -75,6 +75,61 @@ def _phys_index(level: int, nd: int = 81) -> torch.Tensor:
     return torch.tensor(idx, dtype=torch.long)
 
 
+def prepare_params(params: Dict[str, torch.Tensor], variant: str, nd: int = 81) -> Dict[str, torch.Tensor]:
+    """float32 copies of the parameters; PWCDCNet_old's filters re-ordered from its dense-block concatenation order to
+    PWCDCNet's (engine.old_variant_perm), as engine.PwcPlan does."""
+    p = {k: v.detach().float() for k, v in params.items()}
+    if variant == "old":
+        for l in range(2, 7):
+            od = level_in_channels(l, nd)
+            keys = [("conv%d_%d.0.weight" % (l, k), k, 1) for k in range(1, 5)] + [("predict_flow%d.weight" % l, 5, 1)]
+            keys.append(("upfeat%d.weight" % l, 5, 0) if l > 2 else ("dc_conv1.0.weight", 5, 1))
+            for key, k, dim in keys:
+                p[key] = p[key].index_select(dim, old_variant_perm(k, od).to(p[key].device)).contiguous()
+    return p
+
+
+def level_filters(p: Dict[str, torch.Tensor], l: int, nphys: int, nd: int = 81):
+    """Filters of decoder level l re-indexed from the reference's concatenation order to the physical channel order of the c8
+    arena (`nphys` channels): yields (name, weight [Cout, Cin_phys, 3, 3], bias, is_flow_head).  `head%d` is predict_flowL
+    (+ the eight pixel-shuffle phases of upfeatL for l > 2, see the module docstring); level 2 also yields dc_conv1, which
+    reads the same arena."""
+    full = _phys_index(l, nd)
+    od = level_in_channels(l, nd)
+
+    def remap(w, ref_start, phys_start):
+        out = w.new_zeros((w.shape[0], nphys - phys_start, 3, 3))
+        ref = torch.arange(ref_start, ref_start + w.shape[1])
+        out[:, full[ref] - phys_start] = w
+        return out
+
+    ref_start = 448                                      # conv_0 reads corr.. ; each next conv one more dense output
+    for i, co in enumerate(DENSE_OUT):
+        yield "conv%d_%d" % (l, i), remap(p["conv%d_%d.0.weight" % (l, i)], ref_start, ref_start), p["conv%d_%d.0.bias" % (l, i)], False
+        ref_start -= co
+    assert ref_start == 0 and od + 448 == full.numel()
+    wh, bh = p["predict_flow%d.weight" % l], p["predict_flow%d.bias" % l]
+    if l > 2:
+        wu = _deconv_as_conv3x3(p["upfeat%d.weight" % l])            # [8, Cin_ref, 3, 3]
+        k = wh.new_zeros((16, wh.shape[1], 3, 3))
+        k[0:2], k[8:16] = wh, wu
+        bias = bh.new_zeros(16)
+        bias[0:2] = bh
+        bias[8:16] = p["upfeat%d.bias" % l].repeat_interleave(4)
+        yield "head%d" % l, remap(k, 0, 0), bias, True
+    else:
+        yield "head2", remap(wh, 0, 0), bh, True
+        yield "dc_conv1", remap(p["dc_conv1.0.weight"], 0, 0), p["dc_conv1.0.bias"], False
+
+
+def context_filters(p: Dict[str, torch.Tensor]):
+    """dc_conv2..7 (dc_conv1 comes from level_filters(2): it reads the level-2 arena), input channels padded to whole groups."""
+    for i in range(2, 7):
+        w = p["dc_conv%d.0.weight" % i]
+        yield "dc_conv%d" % i, _pad_cin(w, _groups(w.shape[1]) * 8), p["dc_conv%d.0.bias" % i], False
+    yield "dc_conv7", _pad_cin(p["dc_conv7.weight"], 32), p["dc_conv7.bias"], True
+
+
 class PwcPlanF16:
     def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device, md: int = 4,
                  normalize_corr: bool = False, align_corners: bool = False, variant: str = "dc", fuse_pyramid1: bool = True):
@@ -132,14 +187,7 @@ class PwcPlanF16:
             self.b[name] = bias.contiguous().float()
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
 
-        p = {k: v.detach().float() for k, v in params.items()}
-        if variant == "old":                       # same re-ordering as engine.PwcPlan: old concat order -> PWCDCNet's
-            for l in range(2, 7):
-                od = level_in_channels(l, self.nd)
-                keys = [("conv%d_%d.0.weight" % (l, k), k, 1) for k in range(1, 5)] + [("predict_flow%d.weight" % l, 5, 1)]
-                keys.append(("upfeat%d.weight" % l, 5, 0) if l > 2 else ("dc_conv1.0.weight", 5, 1))
-                for key, k, dim in keys:
-                    p[key] = p[key].index_select(dim, old_variant_perm(k, od).to(p[key].device)).contiguous()
+        p = prepare_params(params, variant, self.nd)
         # conv1a (3 -> 16, stride 2) runs straight from the float32 image (ops_f16.image_conv_s2): keep its raw filters
         self.w1a = p["conv1a.0.weight"].contiguous()
         self.b1a = p["conv1a.0.bias"].contiguous()
@@ -157,40 +205,14 @@ class PwcPlanF16:
                 w = p[n + ".0.weight"]
                 put(n, _pad_cin(w, _groups(w.shape[1]) * 8), p[n + ".0.bias"])
         for l in range(2, 7):
-            full = _phys_index(l)
-            nphys = int(self.arena[l].shape[1]) * 8
-            od = level_in_channels(l, self.nd)
-
-            def remap(w, ref_start, phys_start):
-                out = w.new_zeros((w.shape[0], nphys - phys_start, 3, 3))
-                ref = torch.arange(ref_start, ref_start + w.shape[1])
-                out[:, full[ref] - phys_start] = w
-                return out
-
-            ref_start = 448                                      # conv_0 reads corr.. ; each next conv one more dense output
-            for i, co in enumerate(DENSE_OUT):
-                put("conv%d_%d" % (l, i), remap(p["conv%d_%d.0.weight" % (l, i)], ref_start, ref_start), p["conv%d_%d.0.bias" % (l, i)])
-                ref_start -= co
-            assert ref_start == 0 and od + 448 == full.numel()
-            wh, bh = p["predict_flow%d.weight" % l], p["predict_flow%d.bias" % l]
+            for name, w, bias, is_head in level_filters(p, l, int(self.arena[l].shape[1]) * 8, self.nd):
+                put(name, w, bias, split=is_head)
             if l > 2:
-                wu = _deconv_as_conv3x3(p["upfeat%d.weight" % l])            # [8, Cin_ref, 3, 3]
-                k = wh.new_zeros((16, wh.shape[1], 3, 3))
-                k[0:2], k[8:16] = wh, wu
-                bias = bh.new_zeros(16)
-                bias[0:2] = bh
-                bias[8:16] = p["upfeat%d.bias" % l].repeat_interleave(4)
-                put("head%d" % l, remap(k, 0, 0), bias, split=True)
                 # deconvL (2 -> 2 channels) runs in fp32 inside the level-entry kernel: raw ConvTranspose2d parameters
                 self.deconv_w[l] = p["deconv%d.weight" % l].contiguous()
                 self.deconv_b[l] = p["deconv%d.bias" % l].contiguous()
-            else:
-                put("head2", remap(wh, 0, 0), bh, split=True)
-                put("dc_conv1", remap(p["dc_conv1.0.weight"], 0, 0), p["dc_conv1.0.bias"])
-        for i in range(2, 7):
-            w = p["dc_conv%d.0.weight" % i]
-            put("dc_conv%d" % i, _pad_cin(w, _groups(w.shape[1]) * 8), p["dc_conv%d.0.bias" % i])
-        put("dc_conv7", _pad_cin(p["dc_conv7.weight"], 32), p["dc_conv7.bias"], split=True)
+        for name, w, bias, is_head in context_filters(p):
+            put(name, w, bias, split=is_head)
 
     @staticmethod
     def _slots(B: int) -> int:

@@ -1,0 +1,110 @@
+"""Strict half-precision plan of PWCDCNet.forward: ``PWCDCNet(precision="fp16-strict")``.
+
+north_star asks for flow within 1e-3 mean EPE of the reference (models/PWCNet.py:180-273 on the CPU).  The fast half plan
+(engine_f16.PwcPlanF16) sits at ~1.2e-3 of mean |flow| and cannot do better with 11-bit storage everywhere: its error is the sum
+of ~25 rounded tensors per level, and -- worse -- every perturbation of the flows UPSTREAM of a warp can flip warp-mask decisions
+at the 0.9999 threshold (PWCNet.py:174), which makes the error heavy-tailed (single events of 3e-3 in the CPU emulation,
+tests/f16_error_budget.py ``policies``).  This plan removes both effects where they are cheap and keeps half precision where the
+flops are:
+
+  * feature pyramid, decoder levels 6..3 and the level-2 ENTRY (warp + cost volume) run on the fp32 plan (engine.PwcPlan with
+    ``trunk2=False``: Winograd / direct MFMA fp32 kernels, 21 % of the network's multiplications).  Every warp therefore sees
+    the same flow as the fp32 path: no discrete event is ever re-rolled, the remaining error is smooth;
+  * the level-2 dense block, its flow head and the context network -- 79 % of the multiplications -- run in half precision on the
+    c8 kernels with SPLIT FILTERS (hi + lo halves of every filter, ops_f16.pack_conv3x3_f16(split=True): ~22-bit filters, twice
+    the MFMA passes, fp32 accumulation), fp32 flow head and fp32 ``flow2 = predict_flow2 + dc_conv7`` as in the fast plan.  What
+    remains is the rounding of the activations those layers store (level-2 base channels, conv2_*, dc_conv*).
+
+CPU emulation of exactly this policy (pyr/dec6..3 fp32, dec2/ctx split; tests/f16_error_budget.py ``policies fffffss``):
+0.35e-3 / 0.60e-3 / 0.85e-3 / 0.85e-3 on the 64x64, 128x192, 448x1024 and KITTI inputs (fast plan: 0.61 / 1.09 / 1.59 / 1.81).
+Hand-over: the level-2 base channels [corr 81 | c1 32 | up_flow 2 | up_feat 2] are computed in fp32 and converted once to the
+c8 half arena (three pwc_nchw_to_c8_f16 launches).
+
+No autograd; ``flows()`` gives the training-mode 5-tuple (flow3..flow6 straight from the fp32 plan).
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import ops
+from . import ops_f16 as F16
+from .engine import CONTEXT, DENSE_OUT, LEAKY, PYRAMID_CH, PwcPlan
+from .engine_f16 import BASE_G, CORR_G, DENSE_G, _groups, context_filters, level_filters, prepare_params
+
+
+class PwcPlanStrict:
+    def __init__(self, params: Dict[str, torch.Tensor], B: int, H: int, W: int, device: torch.device, md: int = 4,
+                 normalize_corr: bool = False, align_corners: bool = False, variant: str = "dc"):
+        if md != 4:
+            raise NotImplementedError("the half-precision arena is laid out for md=4 (81 cost-volume channels)")
+        # fp32 part: pyramid, levels 6..3, level-2 entry
+        self.upper = PwcPlan(params, B, H, W, device, torch.float32, md, normalize_corr, align_corners, "hip", variant, trunk2=False)
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.nd = 81
+        h2, w2 = H >> 2, W >> 2
+        self.size2 = (h2, w2)
+        g2 = _groups(PYRAMID_CH[2])
+        self.f0 = BASE_G + CORR_G                                   # first group of c1 inside the c8 arena
+        hk = dict(device=device, dtype=torch.float16)
+        self.arena = torch.zeros((B, BASE_G + CORR_G + g2 + 1, h2, w2, 8), **hk)
+        self.ctx = [torch.zeros((B, _groups(c), h2, w2, 8), **hk) for c, _ in CONTEXT]
+        self.head = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
+        self.dc7 = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
+        self.flow_out = torch.empty((B, 2, h2, w2), device=device, dtype=torch.float32)
+
+        self.w: Dict[str, torch.Tensor] = {}
+        self.b: Dict[str, torch.Tensor] = {}
+        self.cin: Dict[str, int] = {}
+        self.cout: Dict[str, int] = {}
+        p = prepare_params(params, variant, self.nd)
+        nphys = int(self.arena.shape[1]) * 8
+        for name, w, bias, _ in list(level_filters(p, 2, nphys, self.nd)) + list(context_filters(p)):
+            self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float(), split=True)       # EVERY layer: hi + lo filters
+            self.b[name] = bias.contiguous().float()
+            self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
+
+    def _conv(self, name, x, out, dilation=1, act=True):
+        F16.conv3x3_f16(x, self.w[name], self.b[name], self.cin[name], self.cout[name], dilation=dilation,
+                        leaky_slope=LEAKY if act else None, out=out, out_f32=out.dtype == torch.float32, split_w=True)
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        up, B = self.upper, self.B
+        if tuple(x.shape) != (B, 6, self.H, self.W) or x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError("plan built for float32 %s on %s, got %s %s on %s" % (
+                (B, 6, self.H, self.W), self.device, x.dtype, tuple(x.shape), x.device))
+        x = ops.densify(x)
+        up.conv_macs = {"direct": 0, "executed": 0}
+        up._pyramid([(x[:, :3], 0, B), (x[:, 3:], B, 2 * B)], 0, 2 * B)
+        for l in (6, 5, 4, 3):
+            up._level_entry(l)
+            up._dense(l)
+            up._heads(l)                      # level 3's heads write up_flow / up_feat into the fp32 level-2 base channels
+        up._level_entry(2)                    # c1 | fused warp + correlation + LeakyReLU, all fp32
+        # hand-over: fp32 NCHW [corr 81 | c1 32 | up_flow 2 | up_feat 2] -> the c8 half arena's corr / c1 / flow groups
+        base = up.arena[2]
+        c = PYRAMID_CH[2]
+        g2 = _groups(c)
+        ar = self.arena
+        F16.to_c8(base[:, 0:81], out=ar[:, BASE_G:BASE_G + CORR_G])
+        F16.to_c8(base[:, 81:81 + c], out=ar[:, self.f0:self.f0 + g2])
+        F16.to_c8(base[:, 81 + c:81 + c + 4], out=ar[:, self.f0 + g2:self.f0 + g2 + 1])
+        # level-2 dense block, flow head, context network: half activations, split filters, fp32 accumulation
+        lo = BASE_G
+        for i, og in enumerate(DENSE_G):
+            self._conv("conv2_%d" % i, ar[:, lo:], ar[:, og:og + DENSE_OUT[i] // 8])
+            lo = og
+        self._conv("head2", ar, self.head, act=False)
+        t = ar
+        for i, (_, dil) in enumerate(CONTEXT):
+            self._conv("dc_conv%d" % (i + 1), t, self.ctx[i], dilation=dil)
+            t = self.ctx[i]
+        self._conv("dc_conv7", t, self.dc7, act=False)
+        torch.add(self.head[:, 0, :, :, 0:2].permute(0, 3, 1, 2), self.dc7[:, 0, :, :, 0:2].permute(0, 3, 1, 2), out=self.flow_out)
+        return self.flow_out
+
+    def flows(self):
+        """(flow2, flow3, flow4, flow5, flow6) of the last run -- the training-mode return (PWCNet.py:270-271)."""
+        f = self.upper.flow
+        return (self.flow_out, f[3], f[4], f[5], f[6])

@@ -71,16 +71,15 @@ def from_c8(x: torch.Tensor, channels: int) -> torch.Tensor:
 
 def pack_conv3x3_f16(weight: torch.Tensor, split: bool = False) -> torch.Tensor:
     """[Cout,Cin,3,3] float32 device tensor -> packed float16 filter bank for conv3x3_f16.
-    split (Cout <= 16): the unused half of the 32-row cout tile carries each filter's rounding residual, i.e. ~22-bit
-    filters at the same MFMA cost -- pass split_w=True to conv3x3_f16 (the 2-channel flow heads use it)."""
+    split: every 32-row cout tile carries 16 filters rounded to half plus their rounding residuals, i.e. ~22-bit filters --
+    pass split_w=True to conv3x3_f16.  For Cout <= 16 (the 2-channel flow heads) the residuals ride in the idle half of the
+    tile at no MFMA cost; wider layers (the strict mode's level-2 / context blocks) pay twice the MFMA passes."""
     _require_device(weight, "weight")
     if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
         raise ValueError("expected float32 [Cout,Cin,3,3], got %s %s" % (weight.dtype, tuple(weight.shape)))
     lib = _lib.load()
     cout, cin = weight.shape[:2]
-    if split and cout > 16:
-        raise ValueError("split filters need Cout <= 16, got %d" % cout)
-    nbytes = lib.pwc_conv3x3_f16_packed_bytes(cin, cout)
+    nbytes = lib.pwc_conv3x3_f16_packed_bytes_split(cin, cout) if split else lib.pwc_conv3x3_f16_packed_bytes(cin, cout)
     wp = torch.empty((nbytes // 2,), dtype=torch.float16, device=weight.device)
     fn = lib.pwc_conv3x3_f16_pack_split if split else lib.pwc_conv3x3_f16_pack
     with torch.cuda.device(weight.device):
@@ -107,9 +106,7 @@ def conv3x3_f16(x: torch.Tensor, wpacked: torch.Tensor, bias: torch.Tensor, cin:
     elif tuple(out.shape) != c8_shape(B, cout, ho, wo):
         raise ValueError("out must be %s" % (c8_shape(B, cout, ho, wo),))
     bsy = _c8_bstride(out, "out", odt)
-    if split_w and cout > 16:
-        raise ValueError("split filters need Cout <= 16, got %d" % cout)
-    need = lib.pwc_conv3x3_f16_packed_bytes(cin, cout)
+    need = lib.pwc_conv3x3_f16_packed_bytes_split(cin, cout) if split_w else lib.pwc_conv3x3_f16_packed_bytes(cin, cout)
     if wpacked.dtype != torch.float16 or wpacked.numel() * 2 != need or wpacked.device != x.device:
         raise ValueError("packed filters do not match Cin=%d Cout=%d" % (cin, cout))
     if bias.dtype != torch.float32 or bias.numel() != cout or bias.device != x.device or not bias.is_contiguous():

@@ -47,6 +47,9 @@ class FlowStream:
             raise PwcHipError("FlowStream needs the model on the ROCm device (parameters are on %s)" % p0.device)
         self.device = p0.device
         self.batch, self.height, self.width = batch, height, width
+        if getattr(net, "precision", "fp32") == "fp16-strict":
+            raise NotImplementedError("FlowStream has plans for precision 'fp32' and 'fp16'; the strict half-precision mode is built "
+                                      "for PWCDCNet.forward (pairs / KITTI stream)")
         if getattr(net, "precision", "fp32") == "fp16":
             from .engine_f16 import PwcVideoPlanF16
             self.plan = PwcVideoPlanF16(params, batch, height, width, self.device, net.md, net.normalize_corr,

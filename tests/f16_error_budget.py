@@ -3,6 +3,7 @@ find which stored tensors carry the EPE of the fp16 path.  
 the only error sources are the roundings switched on below.
 
     python tests/f16_error_budget.py [s|m|full|kitti]
+    python tests/f16_error_budget.py [s|m|m2|m3|full|kitti] policies [codes...]      (round 3: per-block precision policies)
 
 Switches (all True = the round-1 plan):
   w      filters rounded to half                         act    conv outputs (trunk activations) rounded to half
@@ -92,6 +93,109 @@ def forward(sd, x, cfg, all_levels=False):
     return flow2
 
 
+# ---- round 3: per-block precision POLICIES (the strict mode's design study) ---------------------------------------------------------
+# A policy gives every block -- "pyr", "dec6" .. "dec2", "ctx" -- one of
+#   h  half filters and half activations (the fast fp16 plan)          s  split (hi + lo) filters, half activations
+#   f  fp32 block: nothing rounded inside; what it hands to a half block is rounded at the hand-over
+# The flow chain is fp32 in every policy (heads / deconvs unrounded), as in the shipped plan.  Hand-overs: the pyramid features c1_l,
+# c2_l are half wherever decoder level l is a half block (correlation / warp inputs and the c1 slot of the arena); the cost volume,
+# up_flow / up_feat copies are half wherever they are conv inputs of a half block.
+def forward_policy(sd, x, pol, all_levels=False):
+    dt = torch.float64
+    x = x.to(dt)
+
+    def mode_of(name):
+        if name.startswith("dc_"):
+            return pol["ctx"]
+        m = re.match(r"conv(\d)_", name)
+        return pol["dec" + m.group(1)] if m else pol["pyr"]
+
+    def conv(name, t, stride=1, dilation=1, act=True, first=False, mode=None):
+        key = name + ".0" if (name + ".0.weight") in sd else name
+        mode = mode or mode_of(name)
+        w = sd[key + ".weight"].to(dt)
+        if mode == "h" and not first:
+            w = q(w)
+        y = F.conv2d(t, w, sd[key + ".bias"].to(dt), stride=stride, padding=dilation, dilation=dilation)
+        if act:
+            y = O.leaky_relu(y)
+        return q(y) if mode in ("h", "s") else y
+
+    feats = []
+    for im in (x[:, :3], x[:, 3:]):
+        pyr, t = [], im
+        for i, (name, stride) in enumerate(O.PYRAMID):
+            t = conv(name, t, stride=stride, first=(i == 0))
+            if i % 3 == 2:
+                pyr.append(t)
+        feats.append(pyr)
+    flows = {}
+    up_flow = up_feat = None
+    for lvl in (6, 5, 4, 3, 2):
+        half = pol["dec%d" % lvl] in ("h", "s")
+        hq = q if half else (lambda t: t)
+        c1, c2 = hq(feats[0][lvl - 1]), hq(feats[1][lvl - 1])
+        if lvl == 6:
+            xcat = hq(O.leaky_relu(O.correlation(c1, c2, 4, 1, 4, 1, 1, 1)))
+        else:
+            w = O.warp(c2, up_flow * O.WARP_SCALE[lvl])             # fused warp+correlation: the warped features are never stored
+            corr = hq(O.leaky_relu(O.correlation(c1, w, 4, 1, 4, 1, 1, 1)))
+            xcat = torch.cat((corr, c1, hq(up_flow), hq(up_feat)), 1)
+        for i in range(5):
+            xcat = torch.cat((conv("conv%d_%d" % (lvl, i), xcat), xcat), 1)
+        flow = conv("predict_flow%d" % lvl, xcat, act=False, mode="f")
+        flows[lvl] = flow
+        if lvl > 2:
+            up_flow = F.conv_transpose2d(flow, sd["deconv%d.weight" % lvl].to(dt), sd["deconv%d.bias" % lvl].to(dt), stride=2, padding=1)
+            up_feat = F.conv_transpose2d(xcat, sd["upfeat%d.weight" % lvl].to(dt), sd["upfeat%d.bias" % lvl].to(dt), stride=2, padding=1)
+    t = xcat if pol["ctx"] == "f" or pol["dec2"] != "f" else xcat       # (a half ctx block reading an fp32 dec2 arena would round it)
+    if pol["ctx"] != "f" and pol["dec2"] == "f":
+        t = q(xcat)
+    for i, dil in enumerate(O.DILATIONS):
+        t = conv("dc_conv%d" % (i + 1), t, dilation=dil)
+    flow2 = flows[2] + conv("dc_conv7", t, act=False, mode="f")
+    if all_levels:
+        return flow2, flows[3], flows[4], flows[5], flows[6]
+    return flow2
+
+
+POLICIES = [   # name, pyr, dec6, dec5, dec4, dec3, dec2, ctx
+    ("fast plan: everything half", "hhhhhhh"),
+    ("split filters everywhere", "sssssss"),
+    ("pyr f32, rest half", "fhhhhhh"),
+    ("pyr+dec6..3 f32, dec2+ctx half", "ffffhhh"),
+    ("pyr+dec6..3 f32, dec2+ctx split", "fffffss"[:4] + "fss"),
+    ("pyr f32, dec6..4 half, dec3 f32, dec2+ctx split", "fhhhfss"),
+    ("pyr f32, dec6..3 split, dec2+ctx split", "fssssss"),
+    ("pyr split, all split", "sssssss"),
+    ("pyr f32, dec6..4 half, dec3+dec2+ctx split", "fhhhsss"),
+    ("pyr+dec6..3 f32, dec2 split, ctx half", "fffffsh"),
+    ("pyr+dec6..3 f32, dec2 half, ctx split", "fffffhs"),
+    ("all f32 but ctx split", "ffffffs"),
+    ("all f32 but dec2 split", "fffffsf"),
+]
+
+
+def main_policies(which):
+    shape, seed = {"s": ((1, 6, 64, 64), 1234), "m": ((2, 6, 128, 192), 1235), "full": ((1, 6, 448, 1024), 1234),
+                   "kitti": ((1, 6, 384, 1280), 77), "m2": ((2, 6, 128, 192), 4321), "m3": ((2, 6, 192, 256), 99)}[which]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(shape, generator=g, dtype=torch.float32)
+    sd = synthetic_state_dict(O.state_dict_manifest(), seed=0, gain=0.85, bias_std=0.02)
+    torch.set_num_threads(8)
+    names = ("pyr", "dec6", "dec5", "dec4", "dec3", "dec2", "ctx")
+    only = sys.argv[3:]
+    with torch.no_grad():
+        ref = forward_policy(sd, x, dict(zip(names, "fffffff")), all_levels=True)
+        print("== %s  mean|flow2| %.3f" % (which, ref[0].abs().mean().item()), flush=True)
+        for name, code in POLICIES:
+            if only and code not in only:
+                continue
+            out = forward_policy(sd, x, dict(zip(names, code)), all_levels=True)
+            print("%-52s %s EPE flow2 %.3e | " % (name, code, O.epe(out[0], ref[0])) +
+                  " ".join("L%d %.2e" % (l, O.epe(o, r)) for l, o, r in zip((3, 4, 5, 6), out[1:], ref[1:])), flush=True)
+
+
 ALL = ("w", "act", "corr", "warp", "head", "upflow", "flowin", "headw")
 
 
@@ -103,6 +207,8 @@ def cfg_of(on):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "s"
+    if len(sys.argv) > 2 and sys.argv[2] == "policies":
+        return main_policies(which)
     shape, seed = {"s": ((1, 6, 64, 64), 1234), "m": ((2, 6, 128, 192), 1235), "full": ((1, 6, 448, 1024), 1234),
                    "kitti": ((1, 6, 384, 1280), 77)}[which]
     g = torch.Generator().manual_seed(seed)

@@ -63,9 +63,11 @@ def test_abi_argument_errors_without_gpu():
     assert pref(16, 341, 14, 32, 128, 1) == 0 and wsb(16, 341, 14, 32, 128, 1) == 0                 # level 5 (64 tiles) stays on the direct kernel
     assert wsb(16, 565, 112, 256, 128, 1) == 0                                                    # a full grid does not split
     assert pref(16, 96, 112, 256, 64, 16) == 0 and pref(1, 565, 112, 256, 128, 1) == 1            # 7x16 lattices; batch 1 at level 2
-    # split filters (flow heads) exist for Cout <= 16 only
-    assert lib.pwc_conv3x3_f16_pack_split(ctypes.c_void_p(4096), ctypes.c_void_p(4096), 64, 32, None) == -2
-    assert lib.pwc_conv2d_f16_fwd(*([ctypes.c_void_p(4096)] * 4), 1, 64, 8, 8, 32, 1, 1, 16, 0.0, 4096, 4096, None) == -2
+    # split filters: 16 couts per 32-row tile -> twice the rows beyond Cout = 16, the plain size up to there (ABI v8)
+    assert lib.pwc_conv3x3_f16_packed_bytes_split(64, 32) == 2 * lib.pwc_conv3x3_f16_packed_bytes(64, 32)
+    assert lib.pwc_conv3x3_f16_packed_bytes_split(64, 9) == lib.pwc_conv3x3_f16_packed_bytes(64, 9)
+    assert lib.pwc_conv3x3_f16_packed_bytes_split(565, 96) == 36 * 18 * 192 * 16
+    assert lib.pwc_conv3x3_f16_packed_bytes_split(0, 9) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -42,6 +42,12 @@ for name, cin, cout, dil in cases:
     wp16 = ops_f16.pack_conv3x3_f16(w)
     yc = torch.empty(ops_f16.c8_shape(B, cout, H, W), dtype=torch.float16, device=dev)
     ms16 = t(lambda: ops_f16.conv3x3_f16(xc, wp16, b, cin, cout, dilation=dil, out=yc))
+    if os.environ.get("PWC_BENCH_SPLIT") == "1":           # split (hi + lo) filters of the strict mode beside the plain kernel
+        wps = ops_f16.pack_conv3x3_f16(w, split=True)
+        mss = t(lambda: ops_f16.conv3x3_f16(xc, wps, b, cin, cout, dilation=dil, out=yc, split_w=True))
+        print("%-9s %4d->%3d d%-2d  fp16 %8.1f us   split filters %8.1f us (x%.2f, %.1f TFLOP/s executed)"
+              % (name, cin, cout, dil, ms16 * 1e3, mss * 1e3, mss / ms16, 2 * fl / mss / 1e9), flush=True)
+        continue
     if os.environ.get("PWC_BENCH_F16_ONLY") == "1":        # tile sweeps: skip the fp32 comparison
         print("%-9s %4d->%3d d%-2d  fp16 %8.1f us %7.1f TFLOP/s" % (name, cin, cout, dil, ms16 * 1e3, fl / ms16 / 1e9), flush=True)
         continue
