@@ -187,6 +187,10 @@ int pwc_conv2d_f16_fwd(const void *x, const void *wp, const void *bias, void *y,
                        unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream);
 /* layout conversions at the edges of an fp16 pipeline: NCHW f32 <-> c8 f16 (batch strides in elements) */
 int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
+/* the same keeping the rounding residual: y_hi = half(x), y_lo = half(x - y_hi), two c8 tensors of ceil(C/8) groups (strict
+ * half-precision mode: a consumer whose filters are duplicated over both channel sets reads ~22-bit activations) */
+int pwc_nchw_to_c8_f16_hilo(const void *x, void *y_hi, void *y_lo, int B, int C, int H, int W, int64_t x_bstride,
+                            int64_t hi_bstride, int64_t lo_bstride, void *stream);
 int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride, void *stream);
 
 /* First pyramid layer (conv1a: Conv2d(3,16,3,stride 2,pad 1) + LeakyReLU, PWCNet.py:52) from a float32 NCHW image

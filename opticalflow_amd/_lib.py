@@ -57,6 +57,7 @@ SIGNATURES = {
     "pwc_conv2d_f16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),
     "pwc_nchw_to_c8_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "pwc_nchw_to_c8_f16_hilo": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "pwc_c8_f16_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_image_conv_s2_c8_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                          c_int64, c_int64, c_void_p]),

@@ -424,6 +424,30 @@ nchw_to_c8_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, 
     *reinterpret_cast<h8 *>(y + b * bsy + ((int64_t)cg * plane + pix) * 8) = o;
 }
 
+// the same with the rounding residual kept: hi = half(x) into y_hi, lo = half(x - hi) into y_lo (two c8 tensors with the same
+// group count) -- a consumer that gives both channel sets the same filters sees ~22-bit activations (strict mode hand-over)
+__global__ void __launch_bounds__(256)
+nchw_to_c8_hilo_kernel(const float *__restrict__ x, _Float16 *__restrict__ y_hi, _Float16 *__restrict__ y_lo, int C, int Cg,
+                       int64_t plane, int64_t total, int64_t bsx, int64_t bs_hi, int64_t bs_lo) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t pix = i % plane;
+    int64_t t = i / plane;
+    const int cg = (int)(t % Cg);
+    const int64_t b = t / Cg;
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        const float v = (c < C) ? x[b * bsx + (int64_t)c * plane + pix] : 0.f;
+        hi[j] = pwc::sat_half(v);
+        const float r = v - (float)hi[j];                    // exact in fp32; inf - inf cannot occur (hi saturates)
+        lo[j] = (r == r) ? pwc::sat_half(r) : (_Float16)0.f;  // a NaN input is already carried by hi
+    }
+    *reinterpret_cast<h8 *>(y_hi + b * bs_hi + ((int64_t)cg * plane + pix) * 8) = hi;
+    *reinterpret_cast<h8 *>(y_lo + b * bs_lo + ((int64_t)cg * plane + pix) * 8) = lo;
+}
+
 __global__ void __launch_bounds__(256)
 c8_to_nchw_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, int C, int Cg, int64_t plane, int64_t total,
                   int64_t bsx, int64_t bsy) {
@@ -631,6 +655,20 @@ extern "C" int pwc_nchw_to_c8_f16(const void *x, void *y, int B, int C, int H, i
     hipLaunchKernelGGL(nchw_to_c8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float *>(x), static_cast<_Float16 *>(y), C, cg, plane, total, x_bstride, y_bstride);
     return pwc::check_launch("nchw_to_c8_kernel");
+}
+
+extern "C" int pwc_nchw_to_c8_f16_hilo(const void *x, void *y_hi, void *y_lo, int B, int C, int H, int W, int64_t x_bstride,
+                                       int64_t hi_bstride, int64_t lo_bstride, void *stream) {
+    if (!x || !y_hi || !y_lo || B <= 0 || C <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_nchw_to_c8_f16_hilo: bad argument");
+    if (!pwc::aligned16(y_hi) || !pwc::aligned16(y_lo) || (hi_bstride % 8) || (lo_bstride % 8))
+        PWC_FAIL(PWC_EALIGN, "pwc_nchw_to_c8_f16_hilo: outputs must be 16-byte aligned");
+    const int cg = (C + 7) / 8;
+    const int64_t plane = (int64_t)H * W, total = (int64_t)B * cg * plane;
+    if ((total + 255) / 256 > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_nchw_to_c8_f16_hilo: grid too large");
+    hipLaunchKernelGGL(nchw_to_c8_hilo_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(x), static_cast<_Float16 *>(y_hi), static_cast<_Float16 *>(y_lo), C, cg, plane, total,
+                       x_bstride, hi_bstride, lo_bstride);
+    return pwc::check_launch("nchw_to_c8_hilo_kernel");
 }
 
 extern "C" int pwc_c8_f16_to_nchw(const void *x, void *y, int B, int C, int H, int W, int64_t x_bstride, int64_t y_bstride,

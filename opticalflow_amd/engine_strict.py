@@ -13,12 +13,16 @@ flops are:
   * the level-2 dense block, its flow head and the context network -- 79 % of the multiplications -- run in half precision on the
     c8 kernels with SPLIT FILTERS (hi + lo halves of every filter, ops_f16.pack_conv3x3_f16(split=True): ~22-bit filters, twice
     the MFMA passes, fp32 accumulation), fp32 flow head and fp32 ``flow2 = predict_flow2 + dc_conv7`` as in the fast plan.  What
-    remains is the rounding of the activations those layers store (level-2 base channels, conv2_*, dc_conv*).
+    remains is the rounding of the activations those layers store (conv2_*, dc_conv*);
+  * the level-2 BASE channels [corr 81 | c1 32 | up_flow 2 | up_feat 2] -- computed in fp32, read by all seven level-2 consumers
+    -- are handed over as hi + lo halves: the rounding residual of each channel is stored as a second channel set
+    (pwc_nchw_to_c8_f16_hilo) whose filters are copies of the first set's, so those 117 inputs carry ~22 bits (+128 input
+    channels per consumer, +31 % of the level-2 block's MFMA passes).
 
-CPU emulation of exactly this policy (pyr/dec6..3 fp32, dec2/ctx split; tests/f16_error_budget.py ``policies fffffss``):
-0.35e-3 / 0.60e-3 / 0.85e-3 / 0.85e-3 on the 64x64, 128x192, 448x1024 and KITTI inputs (fast plan: 0.61 / 1.09 / 1.59 / 1.81).
-Hand-over: the level-2 base channels [corr 81 | c1 32 | up_flow 2 | up_feat 2] are computed in fp32 and converted once to the
-c8 half arena (three pwc_nchw_to_c8_f16 launches).
+CPU emulation (tests/f16_error_budget.py): policy ``fffffss`` (pyr/dec6..3 fp32, dec2/ctx split) gives 0.35e-3 / 0.60e-3 /
+0.85e-3 / 0.85e-3 on the 64x64, 128x192, 448x1024 and KITTI-sized random inputs (fast plan: 0.61 / 1.09 / 1.59 / 1.81); measured
+on the GPU 0.33 / 0.57 / 0.83e-3 -- and 1.03e-3 on the smooth KITTI-like pair of the tests (mean |flow| 1.63), hence the hi + lo
+base channels (``whatif``: 0.85 -> 0.65e-3 at 448x1024; the rest is conv2_* 0.52, dc_conv* 0.39, adding in quadrature).
 
 No autograd; ``flows()`` gives the training-mode 5-tuple (flow3..flow6 straight from the fp32 plan).
 """
@@ -47,8 +51,9 @@ class PwcPlanStrict:
         self.size2 = (h2, w2)
         g2 = _groups(PYRAMID_CH[2])
         self.f0 = BASE_G + CORR_G                                   # first group of c1 inside the c8 arena
+        self.nbase = CORR_G + g2 + 1                                # groups of [corr | c1 | flow]; the residual set follows it
         hk = dict(device=device, dtype=torch.float16)
-        self.arena = torch.zeros((B, BASE_G + CORR_G + g2 + 1, h2, w2, 8), **hk)
+        self.arena = torch.zeros((B, BASE_G + 2 * self.nbase, h2, w2, 8), **hk)
         self.ctx = [torch.zeros((B, _groups(c), h2, w2, 8), **hk) for c, _ in CONTEXT]
         self.head = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
         self.dc7 = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
@@ -60,7 +65,14 @@ class PwcPlanStrict:
         self.cout: Dict[str, int] = {}
         p = prepare_params(params, variant, self.nd)
         nphys = int(self.arena.shape[1]) * 8
+        hi0, nb = BASE_G * 8, self.nbase * 8
         for name, w, bias, _ in list(level_filters(p, 2, nphys, self.nd)) + list(context_filters(p)):
+            if not name.startswith("dc_conv") or name == "dc_conv1":
+                # consumers of the level-2 arena: column j of w is physical channel (nphys - w.shape[1]) + j; the residual channel
+                # set gets the filters of the set it corrects
+                ps = nphys - w.shape[1]
+                w = w.clone()
+                w[:, hi0 + nb - ps:hi0 + 2 * nb - ps] = w[:, hi0 - ps:hi0 + nb - ps]
             self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float(), split=True)       # EVERY layer: hi + lo filters
             self.b[name] = bias.contiguous().float()
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
@@ -82,14 +94,15 @@ class PwcPlanStrict:
             up._dense(l)
             up._heads(l)                      # level 3's heads write up_flow / up_feat into the fp32 level-2 base channels
         up._level_entry(2)                    # c1 | fused warp + correlation + LeakyReLU, all fp32
-        # hand-over: fp32 NCHW [corr 81 | c1 32 | up_flow 2 | up_feat 2] -> the c8 half arena's corr / c1 / flow groups
+        # hand-over: fp32 NCHW [corr 81 | c1 32 | up_flow 2 | up_feat 2] -> the c8 half arena's corr / c1 / flow groups + residuals
         base = up.arena[2]
         c = PYRAMID_CH[2]
         g2 = _groups(c)
         ar = self.arena
-        F16.to_c8(base[:, 0:81], out=ar[:, BASE_G:BASE_G + CORR_G])
-        F16.to_c8(base[:, 81:81 + c], out=ar[:, self.f0:self.f0 + g2])
-        F16.to_c8(base[:, 81 + c:81 + c + 4], out=ar[:, self.f0 + g2:self.f0 + g2 + 1])
+        nb = self.nbase
+        F16.to_c8_hilo(base[:, 0:81], ar[:, BASE_G:BASE_G + CORR_G], ar[:, BASE_G + nb:BASE_G + nb + CORR_G])
+        F16.to_c8_hilo(base[:, 81:81 + c], ar[:, self.f0:self.f0 + g2], ar[:, self.f0 + nb:self.f0 + nb + g2])
+        F16.to_c8_hilo(base[:, 81 + c:81 + c + 4], ar[:, self.f0 + g2:self.f0 + g2 + 1], ar[:, self.f0 + nb + g2:self.f0 + nb + g2 + 1])
         # level-2 dense block, flow head, context network: half activations, split filters, fp32 accumulation
         lo = BASE_G
         for i, og in enumerate(DENSE_G):

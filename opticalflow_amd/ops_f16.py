@@ -56,6 +56,22 @@ def to_c8(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     return out
 
 
+def to_c8_hilo(x: torch.Tensor, out_hi: torch.Tensor, out_lo: torch.Tensor) -> None:
+    """[B,C,H,W] float32 -> two c8 half tensors: out_hi = half(x), out_lo = half(x - out_hi) (the rounding residual)."""
+    _require_device(x, "x")
+    if x.dim() != 4 or x.dtype != torch.float32 or not x[0].is_contiguous():
+        raise ValueError("x must be float32 [B,C,H,W] with dense planes")
+    B, C, H, W = x.shape
+    for t, n in ((out_hi, "out_hi"), (out_lo, "out_lo")):
+        if tuple(t.shape) != c8_shape(B, C, H, W):
+            raise ValueError("%s must be %s" % (n, c8_shape(B, C, H, W)))
+    bh, bl = _c8_bstride(out_hi, "out_hi"), _c8_bstride(out_lo, "out_lo")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pwc_nchw_to_c8_f16_hilo(x.data_ptr(), out_hi.data_ptr(), out_lo.data_ptr(), B, C, H, W,
+                                                 x.stride(0) if B > 1 else C * H * W, bh, bl, _stream(x))
+    check(rc, "pwc_nchw_to_c8_f16_hilo")
+
+
 def from_c8(x: torch.Tensor, channels: int) -> torch.Tensor:
     """[B,Cg,H,W,8] float16 -> [B,channels,H,W] float32."""
     bsx = _c8_bstride(x, "x")

@@ -119,6 +119,9 @@ def forward_policy(sd, x, pol, all_levels=False):
         y = F.conv2d(t, w, sd[key + ".bias"].to(dt), stride=stride, padding=dilation, dilation=dilation)
         if act:
             y = O.leaky_relu(y)
+        # round-3 what-if switches: "noact": layer-name prefixes whose stored outputs keep full precision (hi + lo storage)
+        if any(name.startswith(pre) for pre in pol.get("noact", ())):
+            return y
         return q(y) if mode in ("h", "s") else y
 
     feats = []
@@ -134,6 +137,8 @@ def forward_policy(sd, x, pol, all_levels=False):
     for lvl in (6, 5, 4, 3, 2):
         half = pol["dec%d" % lvl] in ("h", "s")
         hq = q if half else (lambda t: t)
+        if lvl == 2 and pol.get("base2_exact"):          # what-if: the level-2 base channels (corr, c1, up_flow, up_feat) stored hi + lo
+            hq = lambda t: t
         c1, c2 = hq(feats[0][lvl - 1]), hq(feats[1][lvl - 1])
         if lvl == 6:
             xcat = hq(O.leaky_relu(O.correlation(c1, c2, 4, 1, 4, 1, 1, 1)))
@@ -176,6 +181,33 @@ POLICIES = [   # name, pyr, dec6, dec5, dec4, dec3, dec2, ctx
 ]
 
 
+WHATIF = [   # on top of fffffss
+    ("fffffss", {}),
+    ("+ level-2 base channels exact", {"base2_exact": True}),
+    ("+ conv2_* outputs exact", {"noact": ("conv2_",)}),
+    ("+ dc_conv* outputs exact", {"noact": ("dc_conv",)}),
+    ("+ base exact, conv2_0/1 exact", {"base2_exact": True, "noact": ("conv2_0", "conv2_1")}),
+    ("+ base exact + dc_conv1 exact", {"base2_exact": True, "noact": ("dc_conv1",)}),
+    ("+ base + conv2_* exact", {"base2_exact": True, "noact": ("conv2_",)}),
+]
+
+
+def main_whatif(which):
+    shape, seed = {"s": ((1, 6, 64, 64), 1234), "m": ((2, 6, 128, 192), 1235), "full": ((1, 6, 448, 1024), 1234),
+                   "kitti": ((1, 6, 384, 1280), 77)}[which]
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float32)
+    sd = synthetic_state_dict(O.state_dict_manifest(), seed=0, gain=0.85, bias_std=0.02)
+    torch.set_num_threads(8)
+    names = ("pyr", "dec6", "dec5", "dec4", "dec3", "dec2", "ctx")
+    with torch.no_grad():
+        ref = forward_policy(sd, x, dict(zip(names, "fffffff")))
+        print("== %s  mean|flow2| %.3f" % (which, ref.abs().mean().item()), flush=True)
+        for name, extra in WHATIF:
+            pol = dict(zip(names, "fffffss"))
+            pol.update(extra)
+            print("%-40s EPE flow2 %.3e" % (name, O.epe(forward_policy(sd, x, pol), ref)), flush=True)
+
+
 def main_policies(which):
     shape, seed = {"s": ((1, 6, 64, 64), 1234), "m": ((2, 6, 128, 192), 1235), "full": ((1, 6, 448, 1024), 1234),
                    "kitti": ((1, 6, 384, 1280), 77), "m2": ((2, 6, 128, 192), 4321), "m3": ((2, 6, 192, 256), 99)}[which]
@@ -209,6 +241,8 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "s"
     if len(sys.argv) > 2 and sys.argv[2] == "policies":
         return main_policies(which)
+    if len(sys.argv) > 2 and sys.argv[2] == "whatif":
+        return main_whatif(which)
     shape, seed = {"s": ((1, 6, 64, 64), 1234), "m": ((2, 6, 128, 192), 1235), "full": ((1, 6, 448, 1024), 1234),
                    "kitti": ((1, 6, 384, 1280), 77)}[which]
     g = torch.Generator().manual_seed(seed)

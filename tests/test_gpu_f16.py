@@ -255,8 +255,10 @@ def test_conv3x3_f16_split_filters_fp32_out(dev, cin, cout, H, W):
     assert err_split <= 2e-5 * max(1.0, ref.abs().max().item()) and err_split < 0.1 * err_half
     if cout % 8:
         assert (y32[:, -1, :, :, cout % 8:] == 0).all()
-    with pytest.raises(ValueError):
-        F16.pack_conv3x3_f16(seeded_rand((32, 8, 3, 3), 1).to(dev), split=True)
+    # wider layers pack too since ABI v8 (16 couts per 32-row tile: twice the rows; test_conv3x3_f16_split_filters_any_width)
+    assert F16.pack_conv3x3_f16(seeded_rand((32, 8, 3, 3), 1).to(dev), split=True).numel() == 2 * F16.pack_conv3x3_f16(seeded_rand((32, 8, 3, 3), 1).to(dev)).numel()
+    with pytest.raises(ValueError):                                   # a plain bank passed as a split one: size mismatch
+        F16.conv3x3_f16(xc, F16.pack_conv3x3_f16(seeded_rand((32, cin, 3, 3), 1).to(dev)), torch.zeros(32, device=dev), cin, 32, split_w=True)
 
 
 def test_half_stores_saturate_no_inf_nan(dev):
