@@ -7,14 +7,14 @@
 //
 // One GEMM per transform position p = 0..15:  M_p[cout, tile] = sum_cin U_p[cout, cin] * V_p[cin, tile].
 //   U = G g Gt is computed once per model (pwc_conv3x3_wino_pack) and laid out the way the kernel's LDS wants it;
-//   V = Bt d B is computed in the kernel from the raw input tile (LDS -> registers -> LDS), hidden under the MFMAs;
+//   V = Bt d B is computed in the kernel, in registers, from the raw input tile in LDS, hidden under the MFMAs;
 //   v_mfma_f32_32x32x2_f32: A = U_p (32 couts x 2 cin), B = V_p (2 cin x 32 tiles), D = 32 couts x 32 tiles.
 // A PAIR of waves owns ONE 32-cout block x ONE group of 32 tiles (4 rows x 32 columns of output): 8 of the 16 positions each
 // (8 x 16 = 128 accumulator registers); the output transform At M A swaps one row of M between the two through LDS.
 // Workgroup = 8 waves = MT cout blocks x (4/MT) tile groups; Cin is consumed in chunks of 4 channels (two MFMA k-steps):
 //     iteration k:  barrier | 16 MFMAs per wave on U(k), V(k), with -- one micro-step in the shadow of each MFMA -- the LDS-DMA
-//                   of raw(k+3) and U(k+2) and the transform raw(k+1) -> V(k+1)
-// LDS: raw [3][4][rows+2][34], U [3][16][2][32*MT][2], V [2][tile groups][16][2][32][2]  (98-124 KiB, one workgroup per CU).
+//                   of raw(k+2) and U(k+2), the patch reads of raw(k) and the additions that make V(k)
+// LDS: raw [3][4][rows+2][34], U [3][16][2][32*MT][2]  (54-106 KiB, at least the 64 KiB of the epilogue's exchange; one workgroup per CU).
 // Zero padding, ragged edges and the ragged last channel chunk come from the buffer range check (0 into LDS).
 #include <stdlib.h>
 
@@ -52,9 +52,6 @@ struct Geo {
     static constexpr int kCoutT = 32 * MT;
     static constexpr int kUFloats = 16 * 2 * kCoutT * 2;             // [pos][kh][cout][step]
     static constexpr int kUSlots = kUFloats / 4 / kThreads;          // 16-byte pieces per thread: 2*MT
-    static constexpr int kVGroup = 16 * 2 * 32 * 2;                  // [pos][kh][tile][step]
-    static constexpr int kVFloats = kTG * kVGroup;
-    static constexpr int kSmemBytes = (3 * (kRawRegion + kUFloats) + 2 * kVFloats) * 4;         // raw, U: rings of 3; V: 2
 };
 
 // U[chunk][pos][kh][co][step] <- G g Gt of w[co][cin = chunk*4 + 2*kh + step], zero padded
@@ -93,31 +90,48 @@ wino_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, i
 // ---- EIGHT waves (two per SIMD) ------------------------------------------------------------------------------------------
 // With one wave per SIMD every instruction that is not an MFMA competes with the MFMAs for the wave's single in-order issue
 // slot (a four-wave form with 256 accumulators per wave was measured in round 2: matrix pipe 75 % busy on 128-cout layers, 55 %
-// on 32-cout layers, 3-9 % slower; removed in round 3).  Here the 16
-// positions of a (cout block, tile group) pair are split between two waves (8 positions = 128 accumulator registers each), so
-// the workgroup has 8 waves, two per SIMD, and one wave's LDS-DMA / transform / operand reads issue while the other wave's
-// MFMAs run.  The price is an exchange at the end: At M A needs all four rows of M, each wave of a pair holds two; the
-// waves swap one row each through LDS (M1 one way, M2 the other) and each finishes ONE of the two output rows.
+// on 32-cout layers, 3-9 % slower; removed in round 3).  Here the 16 positions of a (cout block, tile group) pair are split between
+// two waves (8 positions = 128 accumulator registers each), so the workgroup has 8 waves, two per SIMD, and one wave's LDS-DMA /
+// operand work issues while the other wave's MFMAs run.  The price is an exchange at the end: At M A needs all four rows of M, each
+// wave of a pair holds two; the waves swap one row each through LDS (M1 one way, M2 the other) and each finishes ONE of the two
+// output rows.
 constexpr int kThreads8 = 512;
-#ifndef PWC_WINO_EXP
-#define PWC_WINO_EXP 0        // timing experiments (results invalid): 1 no U DMA, 2 no raw DMA, 4 no transform, 8 no barrier/wait
-#endif
+
+// ---- register transform (round 3) ----------------------------------------------------------------------------------------------
+// Round 2's kernel (conv3x3_wino8_kernel, removed) staged V = Bt d B in LDS: every thread turned (channel, tile, row) units of the raw
+// tile into V values one chunk ahead (4 ds_read_b64 + 4 ds_write_b32 per unit).  Here V never exists in LDS: the MFMA B operand of
+// lane (tile n, k-half kh) is V_p[channels 2kh, 2kh+1][tile n] -- a function of that lane's OWN 4x4 patch of those two channels.
+// The lane reads the three patch rows its wave's positions need (12 ds_read_b64 per chunk) and makes its 16 operand values with
+// 32 additions in MFMA shadows.  Gone: the 16 ds_write_b32 + 16 ds_read_b64 per (channel, tile) of the V round trip -- LDS-array
+// cycles per chunk of a 32-cout workgroup 1280 -> ~640 of the 2048 its MFMAs take (ds_write_b32 costs 4 cycles per wave-instruction),
+// the V double buffer (8-32 KiB), and one chunk of pipeline depth (raw(k) is read in iteration k, not transformed one ahead).
+// Same arithmetic in the same order: bit-identical outputs, 1.00-1.19x per layer (32-cout layers +9 %, 64-cout +4..7 %, 128-cout +1 %;
+// profiles/r03_wino_regtr_ab.txt).  The waves of a workgroup that share a tile group repeat the additions (VALU is idle beside the
+// MFMAs); positions are split between the two waves of a pair: wave ph owns rows i = 2ph, 2ph+1 of Bt d B,
+//   Bt rows: 0 = d0 - d2, 1 = d1 + d2, 2 = d2 - d1, 3 = d1 - d3   ->   ph=0: A0 = d0, B0 = d2, Z = d1;  ph=1: A0 = d2, B0 = d1, Z = d3
+//   first row of the wave  w = A0 - B0,  second row  w = B0 + s1 * Z  (s1 = +1 / -1),  then columns (w0-w2, w1+w2, w2-w1, w1-w3).
+template <int MT>
+struct GeoR {
+    using G = Geo<MT>;
+    static constexpr int kRing = 3 * (G::kRawRegion + G::kUFloats) * 4;
+    static constexpr int kExchange = 4 * 2 * 32 * 64 * 4;                     // epilogue: [pair][sender][32][64 lanes] floats
+    static constexpr int kSmemBytes = kRing > kExchange ? kRing : kExchange;
+};
 
 template <int MT>
 __global__ void __launch_bounds__(kThreads8, 1)
-conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
-                     float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil, int co0,
-                     int cps, float *__restrict__ part, int64_t zstride) {
+conv3x3_wino8r_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+                      float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                      int64_t bsx, int64_t bsy, float slope, int do_leaky, int vec2, int dil, int co0,
+                      int cps, float *__restrict__ part, int64_t zstride) {
     using G = Geo<MT>;
     constexpr int TG = G::kTG;
     constexpr int RS = (G::kRawElems + kThreads8 - 1) / kThreads8;        // dword LDS-DMAs per thread and chunk
     constexpr int US = G::kUFloats / 4 / kThreads8;                        // 16-byte LDS-DMAs per thread and chunk (= MT)
-    static_assert(RS * kThreads8 <= G::kRawRegion && US >= 1, "geometry");
+    static_assert(RS * kThreads8 <= G::kRawRegion && US >= 1 && 3 + RS + US <= 16, "geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *raw = smem;                                  // [3][kRawRegion]
     float *ubuf = smem + 3 * G::kRawRegion;             // [3][kUFloats]
-    float *vbuf = ubuf + 3 * G::kUFloats;               // [2][kVFloats]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,11 +140,7 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     const int kh = lane >> 5;
 
     int bid = blockIdx.x;
-    // workgroups i, i+8, ... share an XCD: give each XCD a contiguous run of tiles so that halo re-reads hit its L2
-    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
-    // dilation D: the pixels with (y mod D, x mod D) = (ry, rx) form a lattice on which the layer is an ordinary 3x3
-    // convolution; a workgroup works on one such lattice (innermost in the block index, so the D*D lattices of a region
-    // run together on one XCD) and only its global addresses know about D.  All tile coordinates below are lattice coordinates.
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous runs of tiles
     const int sub = bid % (dil * dil);                  // pixel lattice of a dilated layer
     bid /= dil * dil;
     const int ry = sub / dil, rx = sub % dil;
@@ -138,7 +148,7 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int cb = co0 + (int)blockIdx.y * G::kCoutT;         // first cout of this workgroup
+    const int cb = co0 + (int)blockIdx.y * G::kCoutT;
     const int ox0 = tx * kTW;
     const int oy0 = ty * (kGH * TG);
     const int plane = H * W;
@@ -176,175 +186,142 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
 
     pwc::v4i32 rs_raw, rs_u;
     unsigned base_raw = 0, base_u = 0;
-    auto setup_raw = [&](int chunk, int slot) {
+    auto setup = [&](int chunk, int slot) {                 // descriptors + LDS bases of group {raw(chunk), U(chunk)} -> ring slot
         const int c0 = (c_lo + chunk) * kCK;
         rs_raw = pwc::make_rsrc(xb + (int64_t)c0 * plane, min(kCK, Cin - c0) * plane * 4);
         base_raw = __builtin_amdgcn_readfirstlane(lds_raw + slot * G::kRawRegion * 4);
-    };
-    auto setup_u = [&](int chunk, int slot) {
         rs_u = pwc::make_rsrc(ug + (int64_t)(c_lo + chunk) * uchunk, ubytes);
         base_u = __builtin_amdgcn_readfirstlane(lds_u + slot * G::kUFloats * 4);
     };
-    // transform: a thread makes ONE row i of V = Bt d B per unit (4 of the 16 positions) for one (channel, tile):
-    //   Bt row 0 = d0 - d2, 1 = d1 + d2, 2 = d2 - d1, 3 = d1 - d3  ->  w = ra + sgn * rb with (ra, rb) = (0,2) (1,2) (2,1) (1,3)
-    int src_a[TG], src_b[TG], dst[TG];
-    float sgn[TG];
+    auto issue_all = [&]() {
 #pragma unroll
-    for (int t = 0; t < TG; ++t) {
-        const int u = t * kThreads8 + tid;
-        const int n = u % (32 * TG), c = (u / (32 * TG)) & 3, i = u / (128 * TG);
-        const int tgi = n >> 5, tile = n & 31;
-        const int ra = (i == 0) ? 0 : (i == 2) ? 2 : 1, rb = (i == 2) ? 1 : (i == 3) ? 3 : 2;
-        const int base = c * G::kRawPlane + (kGH * tgi + 2 * (tile >> 4)) * kRawW + 2 * (tile & 15);
-        src_a[t] = base + ra * kRawW;
-        src_b[t] = base + rb * kRawW;
-        sgn[t] = (i == 1) ? 1.f : -1.f;
-        dst[t] = ((tgi * 16 + i * 4) * 2 + (c >> 1)) * 64 + tile * 2 + (c & 1);
-    }
-    f32x2 da[TG][2], db[TG][2];
-    float vo4[TG][4];
-    auto unit_load = [&](int t, int rslot) {
-        const float *p = raw + rslot * G::kRawRegion;
-        da[t][0] = *reinterpret_cast<const f32x2 *>(p + src_a[t]);
-        da[t][1] = *reinterpret_cast<const f32x2 *>(p + src_a[t] + 2);
-        db[t][0] = *reinterpret_cast<const f32x2 *>(p + src_b[t]);
-        db[t][1] = *reinterpret_cast<const f32x2 *>(p + src_b[t] + 2);
-    };
-    auto unit_math = [&](int t) {
-        const float w0 = __builtin_fmaf(sgn[t], db[t][0][0], da[t][0][0]), w1 = __builtin_fmaf(sgn[t], db[t][0][1], da[t][0][1]);
-        const float w2 = __builtin_fmaf(sgn[t], db[t][1][0], da[t][1][0]), w3 = __builtin_fmaf(sgn[t], db[t][1][1], da[t][1][1]);
-        vo4[t][0] = w0 - w2;
-        vo4[t][1] = w1 + w2;
-        vo4[t][2] = w2 - w1;
-        vo4[t][3] = w1 - w3;
-    };
-    auto unit_store = [&](int t, int vslot) {
-        float *vo = vbuf + vslot * G::kVFloats + dst[t];
+        for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads8 * 4, raw_off[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vo[j * 128] = vo4[t][j];
+        for (int j = 0; j < US; ++j) pwc::dma_b128(rs_u, base_u + j * kThreads8 * 16, u_off[j]);
     };
+
+    const int pw = wave >> 1, ph = wave & 1;            // pair (cout block, tile group); position half
+    const int blk = pw % MT, tgw = pw / MT;
+    // this lane's patch: tile n = col -> (tile row col >> 4, tile column col & 15) of tile group tgw, channels 2kh + step
+    const int pbase = 2 * kh * G::kRawPlane + (kGH * tgw + 2 * (col >> 4)) * kRawW + 2 * (col & 15);
+    const int offA = pbase + (2 * ph) * kRawW, offB = pbase + (2 - ph) * kRawW, offZ = pbase + (1 + 2 * ph) * kRawW;
+    const float s1 = ph ? -1.f : 1.f;
+    const int ua_off = (ph * 8 * 2 + kh) * G::kCoutT * 2 + (blk * 32 + col) * 2;          // U of position p0 = 8*ph
 
     f32x16 acc[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[p][j] = 0.f;
-
-    const int pw = wave >> 1, ph = wave & 1;            // pair (cout block, tile group); position half
-    const int blk = pw % MT, tgw = pw / MT;
-    const int ua_off = (ph * 8 * 2 + kh) * G::kCoutT * 2 + (blk * 32 + col) * 2;          // position p0 = 8*ph
-    const int vb_off = tgw * G::kVGroup + ph * 8 * 128 + (kh * 32 + col) * 2;
-    f32x2 a2[2][4], b2[2][4];                           // operand sets: local positions 0..3 -> set 0, 4..7 -> set 1
+    f32x2 a2[2][4], b2[2][4];                           // operand sets: local positions 0..3 -> set 0, 4..7 -> set 1; [.][j] = {step 0, step 1}
 #pragma unroll
     for (int i = 0; i < 4; ++i) a2[1][i] = b2[1][i] = (f32x2){0.f, 0.f};
+    f32x2 rA[2][2], rB[2][2], rZ[2][2];                 // patch rows: [step][columns 0-1 / 2-3]
 
-    // (Giving waves 4..7 -- the second wave of each SIMD -- a schedule with the LDS-DMA and the transform in the other half of
-    // the iteration was measured: no gain, 2.23 vs 2.21 ms on dc_conv1.  The two waves of a SIMD share its issue bandwidth.)
-    auto iteration = [&](int k, int r3, auto full_tag) {
+    // columns of Bt d B from one transformed row w (4 values) of channel `st`, into operand set `set`
+    auto columns = [&](int set, int st, float w0, float w1, float w2, float w3) {
+        b2[set][0][st] = w0 - w2;
+        b2[set][1][st] = w1 + w2;
+        b2[set][2][st] = w2 - w1;
+        b2[set][3][st] = w1 - w3;
+    };
+
+    auto iteration = [&](int k, int r0, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const int r1 = (r3 == 2) ? 0 : r3 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
-        const bool do_raw = (FULL || (k + 3 < nchunks)) && !(PWC_WINO_EXP & 2), do_u = (FULL || (k + 2 < nchunks)) && !(PWC_WINO_EXP & 1),
-                   do_tr = (FULL || (k + 1 < nchunks)) && !(PWC_WINO_EXP & 4);
-        if (!(PWC_WINO_EXP & 8)) {
-            if (FULL || k + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RS + US) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        const float *ua = ubuf + r3 * G::kUFloats + ua_off;
-        const float *vb = vbuf + (k & 1) * G::kVFloats + vb_off;
-        constexpr int kDma0 = 3, kSetup = 2, kTr0 = 2;
+        // ring slots: chunk k in r0 (= k % 3), k+1 in flight -> r1, k+2 issued now -> r2
+        const int r1 = (r0 == 2) ? 0 : r0 + 1, r2 = (r1 == 2) ? 0 : r1 + 1;
+        const bool do_dma = FULL || (k + 2 < nchunks);
+        if (FULL || k + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RS + US) : "memory");      // group k landed, k+1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float *ua = ubuf + r0 * G::kUFloats + ua_off;
+        const float *rw = raw + r0 * G::kRawRegion;
+        constexpr int kSetup = 2, kDma0 = 3;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int q = (s >> 3) - 1, i = s & 7;              // q = -1: local positions 4..7 of the previous chunk (set 1)
             const int pq = (q < 0) ? 1 : 0;
             acc[4 * pq + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[pq][i & 3][i >> 2], b2[pq][i & 3][i >> 2], acc[4 * pq + (i & 3)], 0, 0, 0);
-            if (s < 4) {                                        // operands of local positions 0..3 of this chunk
-                a2[0][s] = *reinterpret_cast<const f32x2 *>(ua + s * (2 * G::kCoutT * 2));
-                b2[0][s] = *reinterpret_cast<const f32x2 *>(vb + s * 128);
-            }
-            if (s >= 8 && s < 12) {                             // ... and of 4..7 (consumed behind the next barrier)
-                a2[1][s - 8] = *reinterpret_cast<const f32x2 *>(ua + (s - 4) * (2 * G::kCoutT * 2));
-                b2[1][s - 8] = *reinterpret_cast<const f32x2 *>(vb + (s - 4) * 128);
-            }
-            if (s == kSetup) {
-                if (do_raw) setup_raw(k + 3, r3);
-                if (do_u) setup_u(k + 2, r2);
-            }
-            if (s >= kDma0 && s < kDma0 + RS) {
-                if (do_raw) pwc::dma_b32(rs_raw, base_raw + (s - kDma0) * kThreads8 * 4, raw_off[s - kDma0]);
-            } else if (s >= kDma0 + RS && s < kDma0 + RS + US) {
-                if (do_u) pwc::dma_b128(rs_u, base_u + (s - kDma0 - RS) * kThreads8 * 16, u_off[s - kDma0 - RS]);
-            }
-            if (do_tr) {
+            if (s < 4) a2[0][s] = *reinterpret_cast<const f32x2 *>(ua + s * (2 * G::kCoutT * 2));            // U of local positions 0..3
+            if (s >= 8 && s < 12) a2[1][s - 8] = *reinterpret_cast<const f32x2 *>(ua + (s - 4) * (2 * G::kCoutT * 2));   // ... 4..7
+            if (s == 0) {
 #pragma unroll
-                for (int t = 0; t < TG; ++t) {
-                    const int phs = s - kTr0 - 3 * t;
-                    if (phs == 0) unit_load(t, r1);
-                    else if (phs == 2) unit_math(t);
-                    else if (phs == 3) unit_store(t, (k + 1) & 1);
+                for (int st = 0; st < 2; ++st) {
+                    rA[st][0] = *reinterpret_cast<const f32x2 *>(rw + offA + st * G::kRawPlane);
+                    rA[st][1] = *reinterpret_cast<const f32x2 *>(rw + offA + st * G::kRawPlane + 2);
                 }
+            }
+            if (s == 1) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    rB[st][0] = *reinterpret_cast<const f32x2 *>(rw + offB + st * G::kRawPlane);
+                    rB[st][1] = *reinterpret_cast<const f32x2 *>(rw + offB + st * G::kRawPlane + 2);
+                }
+            }
+            if (s == 5 || s == 6) {                             // first row of this wave (local positions 0..3): w = A0 - B0
+                const int st = s - 5;
+                columns(0, st, rA[st][0][0] - rB[st][0][0], rA[st][0][1] - rB[st][0][1], rA[st][1][0] - rB[st][1][0], rA[st][1][1] - rB[st][1][1]);
+            }
+            if (s == 7) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    rZ[st][0] = *reinterpret_cast<const f32x2 *>(rw + offZ + st * G::kRawPlane);
+                    rZ[st][1] = *reinterpret_cast<const f32x2 *>(rw + offZ + st * G::kRawPlane + 2);
+                }
+            }
+            if (s == 12 || s == 13) {                           // second row (local positions 4..7): w = B0 + s1 * Z
+                const int st = s - 12;
+                columns(1, st, __builtin_fmaf(s1, rZ[st][0][0], rB[st][0][0]), __builtin_fmaf(s1, rZ[st][0][1], rB[st][0][1]),
+                        __builtin_fmaf(s1, rZ[st][1][0], rB[st][1][0]), __builtin_fmaf(s1, rZ[st][1][1], rB[st][1][1]));
+            }
+            if (s == kSetup && do_dma) setup(k + 2, r2);
+            if (s >= kDma0 && s < kDma0 + RS) {
+                if (do_dma) pwc::dma_b32(rs_raw, base_raw + (s - kDma0) * kThreads8 * 4, raw_off[s - kDma0]);
+            } else if (s >= kDma0 + RS && s < kDma0 + RS + US) {
+                if (do_dma) pwc::dma_b128(rs_u, base_u + (s - kDma0 - RS) * kThreads8 * 16, u_off[s - kDma0 - RS]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // prologue: raw(0) -> V(0); then the two groups the loop expects in flight: {raw(1), U(0)} and {raw(2), U(1)}
-    setup_raw(0, 0);
-#pragma unroll
-    for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads8 * 4, raw_off[j]);
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
-        if (gq + 1 < nchunks) {
-            setup_raw(gq + 1, gq + 1);
-#pragma unroll
-            for (int j = 0; j < RS; ++j) pwc::dma_b32(rs_raw, base_raw + j * kThreads8 * 4, raw_off[j]);
-        }
-        if (gq < nchunks) {
-            setup_u(gq, gq);
-#pragma unroll
-            for (int j = 0; j < US; ++j) pwc::dma_b128(rs_u, base_u + j * kThreads8 * 16, u_off[j]);
-        }
-    }
-    if (nchunks >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (RS + US)) : "memory");     // raw(0) only
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < TG; ++t) {
-        unit_load(t, 0);
-        unit_math(t);
-        unit_store(t, 0);
+    // prologue: the two groups the loop expects in flight, {raw(0), U(0)} and {raw(1), U(1)}
+    setup(0, 0);
+    issue_all();
+    if (nchunks > 1) {
+        setup(1, 1);
+        issue_all();
     }
 #ifndef PWC_WINO_NO_PRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched wave of each SIMD loses every issue arbitration otherwise
 #endif
-    int r3 = 0;
+    int r0 = 0;
     int k = 0;
-    for (; k + 3 < nchunks; ++k) {
-        iteration(k, r3, std::true_type{});
-        r3 = (r3 == 2) ? 0 : r3 + 1;
+    for (; k + 2 < nchunks; ++k) {
+        iteration(k, r0, std::true_type{});
+        r0 = (r0 == 2) ? 0 : r0 + 1;
     }
     for (; k < nchunks; ++k) {
-        iteration(k, r3, std::false_type{});
-        r3 = (r3 == 2) ? 0 : r3 + 1;
+        iteration(k, r0, std::false_type{});
+        r0 = (r0 == 2) ? 0 : r0 + 1;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)               // local positions 4..7 of the last chunk
         acc[4 + (i & 3)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][i & 3][i >> 2], b2[1][i & 3][i >> 2], acc[4 + (i & 3)], 0, 0, 0);
 
-    // ---- output transform: wave ph=0 holds M rows 0,1 (acc[0..3], acc[4..7]), ph=1 rows 2,3.  Row 0 of Y needs
-    // M0 + M1 + M2, row 1 needs M1 - M2 - M3: ph=0 sends M1, ph=1 sends M2, 8 cout rows (32 floats per lane) at a time.
-    const int oy = ry + dil * (oy0 + kGH * tgw + 2 * (col >> 4) + ph);      // the output row this wave finishes
+    // ---- output transform: wave ph=0 holds M rows 0,1 (acc[0..3], acc[4..7]), ph=1 rows 2,3.  Row 0 of Y needs M0 + M1 + M2, row 1
+    // needs M1 - M2 - M3: ph=0 sends M1, ph=1 sends M2, 8 cout rows (32 floats per lane) at a time through LDS.
+    const int oy = ry + dil * (oy0 + kGH * tgw + 2 * (col >> 4) + ph);
     const int ox = rx + dil * (ox0 + 2 * (col & 15));
     const bool inside = (oy < H) && (ox < W);
     const int64_t obase = (int64_t)b * bsy + (int64_t)oy * W + ox;
     float bvs[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) bvs[j] = bias[min(cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh, Cout - 1)];
-    float *xsend = smem + ((pw * 2 + ph) * 32) * 64 + lane;               // [pair][sender][32][64 lanes]
+    float *xsend = smem + ((pw * 2 + ph) * 32) * 64 + lane;
     const float *xrecv = smem + ((pw * 2 + (ph ^ 1)) * 32) * 64 + lane;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        __syncthreads();                      // the rings (round 0) / the previous round's rows are no longer read
+        __syncthreads();
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
@@ -358,7 +335,6 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float other = xrecv[(jj * 4 + c) * 64];
-                // ph 0: M0 + M1 + M2(other);   ph 1: M1(other) - M2 - M3
                 tt[c] = ph ? (other - acc[c][j] - acc[4 + c][j]) : (acc[c][j] + acc[4 + c][j] + other);
             }
             const float bv = part ? 0.f : bvs[j];
@@ -381,15 +357,14 @@ conv3x3_wino8_kernel(const float *__restrict__ x, const float *__restrict__ up, 
         } else if (vec2 == 2) {
             // 16-byte stores: the lanes of two neighbouring tiles (2 + 2 pixels of one row) swap halves -- the even lane ends up
             // with the four pixels of cout j, the odd lane with those of cout j + 1 -- so a lane issues 8 stores instead of 16
-            // (the store tail of a workgroup is issue-bound: MI355X guide, "epilogue store tail")
             const int odd = lane & 1;
 #pragma unroll
             for (int jj = 0; jj < 8; jj += 2) {
                 const int j = 8 * r + jj;
-                const float s0 = odd ? ya[jj] : ya[jj + 1], s1 = odd ? yb[jj] : yb[jj + 1];
-                const float r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const float s0 = odd ? ya[jj] : ya[jj + 1], sB = odd ? yb[jj] : yb[jj + 1];
+                const float q0 = __shfl_xor(s0, 1), q1 = __shfl_xor(sB, 1);
                 const int co = cb + blk * 32 + (j & 3) + 8 * (j >> 2) + 4 * kh + odd;
-                const f32x4 v = odd ? (f32x4){r0, r1, ya[jj + 1], yb[jj + 1]} : (f32x4){ya[jj], yb[jj], r0, r1};
+                const f32x4 v = odd ? (f32x4){q0, q1, ya[jj + 1], yb[jj + 1]} : (f32x4){ya[jj], yb[jj], q0, q1};
                 if (inside && co < Cout) *reinterpret_cast<f32x4 *>(y + obase - 2 * odd + (int64_t)co * plane) = v;
             }
         } else {
@@ -425,15 +400,15 @@ int launch_wino(const float *x, const float *up, const float *bias, float *y, in
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino_fwd: grid too large");
     int vec2 = dil == 1 && (W % 2 == 0) && (bsy % 2 == 0) && !(reinterpret_cast<uintptr_t>(y) & 7u);
     if (vec2 && (W % 4 == 0) && (bsy % 4 == 0) && !(reinterpret_cast<uintptr_t>(y) & 15u)) vec2 = 2;      // 16-byte stores (8-wave kernel)
-    static pwc::LdsAttrOnce once8;
-    if (const int rc = pwc::ensure_lds_attr(once8, reinterpret_cast<const void *>(&conv3x3_wino8_kernel<MT>), G::kSmemBytes,
-                                            "conv3x3_wino8_kernel"))
+    static pwc::LdsAttrOnce once8r;
+    if (const int rc = pwc::ensure_lds_attr(once8r, reinterpret_cast<const void *>(&conv3x3_wino8r_kernel<MT>), GeoR<MT>::kSmemBytes,
+                                            "conv3x3_wino8r_kernel"))
         return rc;
-    hipLaunchKernelGGL(conv3x3_wino8_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups, (unsigned)ksplit), dim3(kThreads8), G::kSmemBytes, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, vec2, dil, co0,
-                       cps, part, (int64_t)B * Cout * H * W);
-    pwc::note_kernel("conv3x3_wino8_kernel", MT, G::kTG, 1, dil, 1, 0);
-    return pwc::check_launch("conv3x3_wino8_kernel");
+    hipLaunchKernelGGL(conv3x3_wino8r_kernel<MT>, dim3((unsigned)nblk, (unsigned)ngroups, (unsigned)ksplit), dim3(kThreads8),
+                       GeoR<MT>::kSmemBytes, st, x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky,
+                       vec2, dil, co0, cps, part, (int64_t)B * Cout * H * W);
+    pwc::note_kernel("conv3x3_wino8r_kernel", MT, G::kTG, 1, dil, 1, 0);
+    return pwc::check_launch("conv3x3_wino8r_kernel");
 }
 
 // Launch shape of a layer run with ONE cout-tile width (the widest that divides CoutP), and its split-K plan: a launch that leaves
@@ -456,7 +431,8 @@ WinoPlan wino_plan(int B, int Cin, int H, int W, int Cout, int dilation) {
     static const int knob = [] { const char *e = getenv("PWC_WINO_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
     // measured (tools/bench_wino.py layers): with 64 workgroups (level 5 at batch 16) the split form only ties the direct kernel's own
     // split-K; from ~100 (conv4_3: 128) it wins 1.35x
-    if (knob != 0 && p.nwg < 160 && p.nwg >= 96) {
+    // ... and only with a long K: conv5aa/b (128 -> 128 @14x32, 32 chunks) in three slices lost to the direct kernel (52 vs 48 us)
+    if (knob != 0 && p.nwg < 160 && p.nwg >= 96 && (nchunks >= 64 || knob > 0)) {
         int ks = (int)((320 + p.nwg - 1) / p.nwg);
         if (knob > 0) ks = knob;
         ks = ks < nchunks / 8 ? ks : nchunks / 8;
