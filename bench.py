@@ -85,7 +85,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PWC_BENCH_CPU_THREADS", "16"))))
 
 
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 
 
 def pmc_record(key, applies):
@@ -142,15 +142,22 @@ def probes_fp32(result, args, plan, B, H, W, h2, w2, stream):
         direct_flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
         ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), PROBE_REPS, stream)
         kern = last_conv_kernel()
-        wino = "wino" in kern
-        # The roofline that bounds the kernel counts the multiplications it EXECUTES: the Winograd route does 16 per 2x2
-        # outputs and 4-channel chunk instead of 36 (Cin padded to the chunk); the direct-convolution equivalent is reported
-        # beside it and may exceed the fp32 MFMA peak -- that is the point of the algorithm, not a measurement error.
-        flops = 2.0 * 16 * 128 * (-(-cin // 4) * 4) * (-(-h2 // 2)) * (-(-w2 // 2)) * B if wino else direct_flops
+        wino, wino4 = "wino" in kern, "wino4" in kern
+        # The roofline that bounds the kernel counts the multiplications it EXECUTES: Winograd F(2x2,3x3) does 16 per 2x2 outputs,
+        # F(4x4,3x3) 36 per 4x4 outputs (instead of 36 / 144 for the direct form), per REAL input channel (the zero channels that pad
+        # the last 4-channel chunk are not work); the direct-convolution equivalent is reported beside it and exceeds the fp32 MFMA
+        # peak -- that is the point of the algorithm, not a measurement error.
+        if wino4:
+            flops = 2.0 * 36 * 128 * cin * (-(-h2 // 4)) * (-(-w2 // 4)) * B
+        elif wino:
+            flops = 2.0 * 16 * 128 * cin * (-(-h2 // 2)) * (-(-w2 // 2)) * B
+        else:
+            flops = direct_flops
         ach = flops / (ms * 1e-3) / 1e12
-        rec = pmc_record("conv3x3_wino_dc_conv1_b16" if wino else "conv3x3_mfma_dc_conv1_b16", full)
+        rec = pmc_record("conv3x3_wino4_dc_conv1_b16" if wino4 else "conv3x3_wino_dc_conv1_b16" if wino else "conv3x3_mfma_dc_conv1_b16", full)
         result["roofline"] = {"kernel": "%s = %s (dc_conv1 %d->128 @%dx%d, B=%d)"
-                                        % (kern, "<cout blocks, tile groups> Winograd F(2x2,3x3), fp32" if wino else
+                                        % (kern, "<cout blocks, tile groups> Winograd F(4x4,3x3), fp32" if wino4 else
+                                           "<cout blocks, tile groups> Winograd F(2x2,3x3), fp32" if wino else
                                            "<MT,NT,stride,dilation,two-per-CU,split-K>", cin, w2, h2, B),
                               "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": rec.get("traffic"),

@@ -167,6 +167,20 @@ int pwc_conv3x3_wino_fwd(const void *x, const void *up, const void *bias, void *
  * pwc_conv3x3_wino_workspace_bytes() bytes, shareable with pwc_conv2d_fwd's workspace on one stream; without it the layer runs unsplit */
 int64_t pwc_conv3x3_wino_workspace_bytes(int B, int Cin, int H, int W, int Cout, int dilation);
 
+/* The same operator by Winograd F(4x4,3x3) (csrc/pwc_conv_wino4.hip, round 3): 36 multiplications per 4x4 outputs -- 1.78x fewer
+ * MFMA passes than F(2x2,3x3) -- at ~6x (rms) the fp32 rounding error of F(2x2) (4e-5 instead of 2e-6 at the largest on unit-scale
+ * data with 565 input channels).  Dilation 1, W % 4 == 0, 16-byte aligned x / y with batch strides that are multiples of 4
+ * (PWC_EUNSUPPORTED / PWC_EALIGN otherwise).  up = pwc_conv3x3_wino4_pack(w): G g Gt (6x6 per filter, computed in double) in the
+ * kernel's LDS order [chunk of 4 cin][9 groups of 4 positions][cin][CoutP][4], pwc_conv3x3_wino4_packed_bytes() bytes (4x the filter).
+ * pwc_conv3x3_wino4_preferred: the measured rule for when this route beats pwc_conv3x3_wino_fwd (large, well-filled maps).
+ * flags: PWC_ACT_LEAKY. */
+int64_t pwc_conv3x3_wino4_packed_bytes(int Cin, int Cout);
+int pwc_conv3x3_wino4_preferred(int B, int Cin, int H, int W, int Cout, int dilation);
+int pwc_conv3x3_wino4_pack(const void *w, void *up, int Cin, int Cout, void *stream);
+int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *bias, void *y,
+                          int B, int Cin, int H, int W, int Cout, int dilation, unsigned flags, float leaky_slope,
+                          int64_t x_bstride, int64_t y_bstride, void *stream);
+
 /* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------
  * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch
  * stride (in halves, multiple of 8) is free, so a tensor may be a channel-group slice of an arena.  fp32

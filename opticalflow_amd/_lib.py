@@ -54,6 +54,11 @@ SIGNATURES = {
     "pwc_conv3x3_wino_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
                              c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "pwc_conv3x3_wino_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pwc_conv3x3_wino4_packed_bytes": (c_int64, [c_int, c_int]),
+    "pwc_conv3x3_wino4_preferred": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pwc_conv3x3_wino4_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "pwc_conv3x3_wino4_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
+                                     c_int64, c_int64, c_void_p]),
     "pwc_conv2d_f16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),
     "pwc_nchw_to_c8_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),

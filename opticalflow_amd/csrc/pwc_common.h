@@ -101,6 +101,12 @@ __device__ __forceinline__ void dma_b128_nt(v4i32 rsrc, unsigned lds_base, unsig
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds"
                  :: "s"(lds_base), "v"(voffset), "s"(rsrc) : "memory");
 }
+// 16-byte pieces with a wave-uniform extra byte offset in an SGPR (added to the address, NOT part of the range check):
+// one per-lane offset register serves every instruction of a stream whose pieces are `soffset` apart
+__device__ __forceinline__ void dma_b128_so(v4i32 rsrc, unsigned lds_base, unsigned voffset, unsigned soffset) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
 __device__ __forceinline__ void dma_b32(v4i32 rsrc, unsigned lds_base, unsigned voffset) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
                  :: "s"(lds_base), "v"(voffset), "s"(rsrc) : "memory");

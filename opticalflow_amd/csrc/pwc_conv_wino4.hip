@@ -1,0 +1,510 @@
+// 3x3 / stride 1 convolution by Winograd F(4x4,3x3) on the gfx950 matrix cores, fp32 throughout (round 3).
+// Same operator as pwc_conv_wino.hip (nn.Conv2d(3x3, padding = dilation) + LeakyReLU, reference models/PWCNet.py:26-33) with
+// 36 multiplications per 4x4 outputs instead of 64 (F(2x2)) or 144 (direct): 1.78x fewer MFMA passes than F(2x2,3x3).
+//
+//     Y(4x4) = At [ sum_cin (G g Gt) (.) (Bt d B) ] A        d = 6x6 input patch, g = 3x3 filter, points 0, +-3/4, +-3/2, inf
+//
+// The price is accuracy: the Winograd-domain products are large and mostly cancel in At M A, so the fp32 accumulation over Cin
+// leaves ~3x (rms) / ~5x (max) the error of F(2x2) against an fp64 convolution (with the textbook points 0, +-1, +-2 it is 6x / 17x).
+// The route is therefore GATED: pwc_conv3x3_wino4_preferred() only says yes for the large level-2 / level-3 layers, the per-layer
+// error stays inside the tests' 3e-6*sqrt(9 Cin) bound with margin, and the whole-forward EPE against the oracle is asserted at 1e-4.
+//
+// Design -- everything a (cout, tile) pair needs lives in ONE lane, so there is no cross-wave exchange at all:
+//   v_mfma_f32_16x16x4_f32: A = U_p[16 couts][4 cin], B = V_p[4 cin][16 tiles], D = 16 couts x 16 tiles = 4 accumulator registers
+//   per lane and position; a wave owns one (16-cout block, 16-tile group) and ALL 36 positions = 144 accumulator registers.
+//   Lane (n = lane % 16, k = lane / 16): channel k of the 4-channel chunk, tile n of the group.
+//     B operand: the lane reads ITS 6x6 patch of channel k (6 x (ds_read_b128 + ds_read_b64)) and makes the 36 values of
+//                Bt d B itself -- 12 fused multiply-adds per 1-D transform, rows first (one patch row per phase, one chunk
+//                ahead), then one column per phase right before the six MFMAs that consume it;
+//     A operand: U in LDS as [position / 4][cin][cout][position % 4]: four positions per ds_read_b128, conflict-free;
+//     epilogue : At M A for the lane's 4 couts x 1 tile in registers, bias, LeakyReLU, four 16-byte stores per cout.
+//   Workgroup = 8 waves = CB cout blocks x TG tile groups (<4,2>: 64 couts x 8 rows x 64 columns; <2,4>: 32 couts x 16 x 64);
+//   a tile group is one row of sixteen 4x4 tiles.  Cin runs in chunks of 4 channels through LDS rings of three slots filled by
+//   LDS-DMA in 16-byte pieces: raw input tile [4][4 TG + 2 rows][72] (global columns ox0 - 4 .. ox0 + 67; the range check
+//   supplies padding, edges and the ragged last chunk), U [9][4][16 CB][4].  Dilation 1 only.  One barrier per chunk:
+//     iteration k:  wait {raw(k+1), U(k)} | 36 MFMAs on U(k), V(k) | issue raw(k+3), U(k+2) | rows of raw(k+1) -> w(k+1)
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "pwc_common.h"
+
+#ifndef PWC_W4_EXP
+#define PWC_W4_EXP 0          // timing experiments, tools/wino4_exp.sh (results invalid): 1 = every U fetch reads chunk 0, 2 = every raw fetch reads
+#endif                        // chunk 0, 4 = no LDS-DMA inside the loop, 8 = no input transforms, 16 = no barrier / counted wait, 32 = no patch-row reads
+
+namespace {
+
+using pwc::leaky;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 512;
+constexpr int kCK = 4;               // input channels per chunk = K of one MFMA
+constexpr int kGW = 64;              // output columns of a tile group (16 tiles of 4)
+constexpr int kRowP = 18;            // 16-byte pieces per staged row: global columns ox0 - 4 .. ox0 + 67
+constexpr int kRawW = 4 * kRowP;     // 72 floats; the row lands ONE float to the right of a 16-byte LDS boundary, so that global
+                                     // column ox0 - 1 (the first patch column) sits at index 4: every patch row is 16-byte aligned
+constexpr unsigned kOOB = 0x80000000u;
+
+template <int CB, int TG>
+struct Geo4 {
+    static_assert(CB * TG == 8, "eight waves");
+    static constexpr int kRows = 4 * TG + 2;
+    static constexpr int kPP = (kRows * kRowP + 15) / 16 * 16;        // pieces per staged channel, padded: planes are multiples of 64 floats
+    static constexpr int kPlane = 4 * kPP;
+    static constexpr int kRawPieces = kCK * kPP;
+    static constexpr int kRawFloats = kCK * kPlane + 4;               // + the one-float shift (kept 16-byte granular)
+    static constexpr int kCoutT = 16 * CB;
+    static constexpr int kUFloats = 36 * kCK * kCoutT;                // [9][4 cin][cout][4 positions]
+    static constexpr int kUPieces = kUFloats / 4;                     // 16-byte pieces
+    static constexpr int kSlot = kRawFloats + kUFloats;
+    static constexpr int kSmemBytes = 3 * kSlot * 4;
+    // LDS-DMA instructions per thread and chunk; the last one of each stream is issued by the first kTail / 64 waves only
+    static constexpr int kRS = (kRawPieces + kThreads - 1) / kThreads, kRawTail = kRawPieces % kThreads;
+    static constexpr int kUS = (kUPieces + kThreads - 1) / kThreads, kUTail = kUPieces % kThreads;
+    static_assert(kRawTail % 64 == 0 && kUTail % 64 == 0, "tails are whole waves");
+    static constexpr int kRawWaves = kRawTail ? kRawTail / 64 : 8, kUWaves = kUTail ? kUTail / 64 : 8;   // waves that issue the last instruction
+    static_assert(kSmemBytes <= 160 * 1024, "LDS");
+    static_assert(kThreads % kCoutT == 0, "one U offset register: instruction j is j * (kThreads / kCoutT) rows further");
+};
+
+// Interpolation points 0, +-a, +-b, inf with a = 3/4, b = 3/2 instead of the textbook 0, +-1, +-2: the same operation count, every
+// constant exact in binary, and -- measured in fp32 on 565 input channels of unit-scale data -- 2.2x less rms / 4.4x less maximum
+// error (the error of F(4,3) is dominated by the fp32 accumulation of large, mostly cancelling Winograd-domain products; these
+// points balance the magnitudes of the 36 positions; a scan over (a, b) is recorded in profiles/r03_wino4_notes.md).
+constexpr float kA = 0.75f, kB = 1.5f;
+constexpr float kA2 = kA * kA, kB2 = kB * kB, kA2B2 = kA2 * kB2, kS2 = kA2 + kB2, kA3 = kA2 * kA, kB3 = kB2 * kB;
+
+// 1-D input transform, rows of Bt = coefficients of prod_{k != j} (x - a_k) (12 operations):
+//   t0 = a2b2 d0 - (a2 + b2) d2 + d4                      t5 = a2b2 d1 - (a2 + b2) d3 + d5
+//   t1, t2 = (d4 - b2 d2) +- a (d3 - b2 d1)               t3, t4 = (d4 - a2 d2) +- b (d3 - a2 d1)
+__device__ __forceinline__ void bt6(const float (&d)[6], float (&t)[6]) {
+#if defined(PWC_W4_EXP) && (PWC_W4_EXP & 8)
+    for (int i = 0; i < 6; ++i) t[i] = d[i];
+    return;
+#endif
+    t[0] = __builtin_fmaf(kA2B2, d[0], __builtin_fmaf(-kS2, d[2], d[4]));
+    const float p = __builtin_fmaf(-kB2, d[2], d[4]), q = __builtin_fmaf(-kB2, d[1], d[3]);
+    t[1] = __builtin_fmaf(kA, q, p);
+    t[2] = __builtin_fmaf(-kA, q, p);
+    const float r = __builtin_fmaf(-kA2, d[2], d[4]), s = __builtin_fmaf(-kA2, d[1], d[3]);
+    t[3] = __builtin_fmaf(kB, s, r);
+    t[4] = __builtin_fmaf(-kB, s, r);
+    t[5] = __builtin_fmaf(kA2B2, d[1], __builtin_fmaf(-kS2, d[3], d[5]));
+}
+
+// The same transform in three parts of four operations (one part per MFMA shadow: an MFMA of 32 cycles hides ~24 cycles of other
+// vector issue, i.e. at most six VALU operations; twelve in one gap cost 24 cycles each time), each pinned where it is written.
+template <int PART>
+__device__ __forceinline__ void bt6_part(const float (&d)[6], float (&t)[6]) {
+#if defined(PWC_W4_EXP) && (PWC_W4_EXP & 8)
+    t[2 * PART] = d[2 * PART]; t[(2 * PART + 5) % 6] = d[PART];
+    return;
+#endif
+    if constexpr (PART == 0) {
+        t[0] = __builtin_fmaf(kA2B2, d[0], __builtin_fmaf(-kS2, d[2], d[4]));
+        t[5] = __builtin_fmaf(kA2B2, d[1], __builtin_fmaf(-kS2, d[3], d[5]));
+        asm volatile("" : "+v"(t[0]), "+v"(t[5]));
+    } else if constexpr (PART == 1) {
+        const float p = __builtin_fmaf(-kB2, d[2], d[4]), q = __builtin_fmaf(-kB2, d[1], d[3]);
+        t[1] = __builtin_fmaf(kA, q, p);
+        t[2] = __builtin_fmaf(-kA, q, p);
+        asm volatile("" : "+v"(t[1]), "+v"(t[2]));
+    } else {
+        const float r = __builtin_fmaf(-kA2, d[2], d[4]), s = __builtin_fmaf(-kA2, d[1], d[3]);
+        t[3] = __builtin_fmaf(kB, s, r);
+        t[4] = __builtin_fmaf(-kB, s, r);
+        asm volatile("" : "+v"(t[3]), "+v"(t[4]));
+    }
+}
+
+// The optimiser sinks pure arithmetic towards its first use: without this pin the six row transforms of an iteration (whose results
+// are consumed one iteration later) all ended up in ONE MFMA shadow of the next iteration -- 72 VALU operations in a row and 36
+// patch values kept alive across the barrier (spills).  An empty volatile asm that "modifies" the values keeps them where they are.
+__device__ __forceinline__ void pin6(float (&t)[6]) {
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+}
+
+// 1-D output transform, At[i][j] = a_j^i:  o0 = m0 + (m1 + m2) + (m3 + m4);  o1 = a (m1 - m2) + b (m3 - m4);
+//   o2 = a2 (m1 + m2) + b2 (m3 + m4);  o3 = a3 (m1 - m2) + b3 (m3 - m4) + m5
+__device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4]) {
+    const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+    o[0] = (m[0] + s1) + s2;
+    o[1] = __builtin_fmaf(kB, d2, kA * d1);
+    o[2] = __builtin_fmaf(kB2, s2, kA2 * s1);
+    o[3] = __builtin_fmaf(kB3, d2, kA3 * d1) + m[5];
+}
+
+// U[chunk][g = p / 4][k][co][p % 4] <- (G g Gt)[i][j] of w[co][cin = 4 chunk + k], position p = 6 j + i (column-major: the kernel
+// consumes one column j of the 6x6 position grid per phase); computed in double, stored as float; zero outside Cin / Cout
+__global__ void __launch_bounds__(256)
+wino4_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, int Cout, int CoutP, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int pl = (int)(idx & 3);
+    int64_t t = idx >> 2;
+    const int co = (int)(t % CoutP);
+    t /= CoutP;
+    const int k = (int)(t & 3);
+    t >>= 2;
+    const int g = (int)(t % 9);
+    const int chunk = (int)(t / 9);
+    const int p = 4 * g + pl, i = p % 6, j = p / 6;
+    const int cin = chunk * kCK + k;
+    double v = 0.0;
+    if (co < Cout && cin < Cin) {
+        // G[j] = (1, a_j, a_j^2) / prod_{k != j} (a_j - a_k) for the finite points 0, +-a, +-b; (0, 0, 1) for the point at infinity
+        const double a = kA, bb = kB, na = 2 * a * a * (a * a - bb * bb), nb = 2 * bb * bb * (bb * bb - a * a);
+        const double G[6][3] = {{1.0 / (a * a * bb * bb), 0.0, 0.0}, {1.0 / na, a / na, a * a / na}, {1.0 / na, -a / na, a * a / na},
+                                {1.0 / nb, bb / nb, bb * bb / nb}, {1.0 / nb, -bb / nb, bb * bb / nb}, {0.0, 0.0, 1.0}};
+        const float *gw = w + ((int64_t)co * Cin + cin) * 9;
+        for (int a = 0; a < 3; ++a) {
+            double r = 0.0;
+            for (int b = 0; b < 3; ++b) r += (double)gw[a * 3 + b] * G[j][b];
+            v += G[i][a] * r;
+        }
+    }
+    up[idx] = (float)v;
+}
+
+#define PWC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+
+template <int CB, int TG>
+__global__ void __launch_bounds__(kThreads, 1)
+conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+                     float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0) {
+    using G = Geo4<CB, TG>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 3 x [raw | U]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int n = lane & 15;                  // tile of the group (B / D column)
+    const int kq = lane >> 4;                 // channel of the chunk (A / B k index); D rows 4 kq .. 4 kq + 3
+    const int cbi = wave % CB, tgi = wave / CB;
+
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous runs of tiles
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int cb0 = co0 + (int)blockIdx.y * G::kCoutT;
+    const int ox0 = tx * kGW;
+    const int oy0 = ty * (4 * TG);
+    const int plane = H * W;
+
+    // ---- per-lane LDS-DMA source offsets -------------------------------------------------------------
+    // waves are numbered so that the raw and the U tails are issued by the first kRawWaves / kUWaves waves
+    unsigned raw_off[G::kRS];
+#pragma unroll
+    for (int j = 0; j < G::kRS; ++j) {
+        const int i = j * kThreads + tid;                 // piece (channel c, row, q) of the padded [4][kPP] image
+        const int c = i / G::kPP;
+        const int rem = i % G::kPP;
+        const int row = rem / kRowP, q = rem % kRowP;
+        const int iy = oy0 - 1 + row;
+        const int ix = ox0 - 4 + 4 * q;                   // W % 4 == 0: a piece is all-in or all-out
+        const bool ok = (i < G::kRawPieces) && (row < G::kRows) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+        raw_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
+    }
+    // U piece p = j * kThreads + tid = (row r = p / CoutT of the [36][CoutT] image, cout c): instruction j reads rows kThreads / CoutT
+    // further down -> one per-lane offset + a wave-uniform byte offset per instruction
+    const unsigned u_off = (unsigned)((tid / G::kCoutT) * CoutP + tid % G::kCoutT) * 16u;
+    const unsigned u_step = (unsigned)(kThreads / G::kCoutT) * (unsigned)CoutP * 16u;
+
+    const float *xb = x + (int64_t)b * bsx;
+    const int nchunks = (Cin + kCK - 1) / kCK;
+    const int64_t uchunk = (int64_t)36 * kCK * CoutP;                 // floats per chunk of the packed image
+    const float *ug = up + (int64_t)cb0 * 4;
+    const int ubytes = (int)(uchunk - (int64_t)cb0 * 4) * 4;
+    const unsigned lds0 = pwc::lds_addr(smem);
+
+#if 0
+#define PWC_W4_EXP_UNUSED 0          // timing experiments (results invalid): 1 = every U fetch reads chunk 0, 2 = every raw fetch reads chunk 0,
+                              // 4 = no LDS-DMA inside the loop, 8 = no input transforms (bt6), 16 = no barrier / counted wait, 32 = no patch-row reads
+#endif
+    auto issue_raw = [&](int chunk) {                                 // raw(chunk) -> slot chunk % 3, one float to the right
+        // a chunk past the end gets a zero-sized descriptor: every lane fails the range check, nothing is fetched, zeros land in a slot
+        // nobody reads -- so EVERY iteration issues a whole group and the counted waits never change
+        const int c0 = (PWC_W4_EXP & 2) ? 0 : chunk * kCK;
+        const pwc::v4i32 rs = pwc::make_rsrc(xb + (int64_t)min(c0, Cin - 1) * plane, max(0, min(kCK, Cin - c0)) * plane * 4);
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (chunk % 3) * G::kSlot * 4 + 4 + wave * 1024);
+#pragma unroll
+        for (int j = 0; j < G::kRS; ++j)
+            if (j < G::kRS - 1 || wave < G::kRawWaves) pwc::dma_b128(rs, base + j * kThreads * 16, raw_off[j]);
+    };
+    auto issue_u = [&](int chunk) {                                   // U(chunk) -> slot chunk % 3
+        const pwc::v4i32 rs = pwc::make_rsrc(ug + ((PWC_W4_EXP & 1) ? 0 : (int64_t)min(chunk, nchunks - 1) * uchunk), chunk < nchunks ? ubytes : 0);
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + ((chunk % 3) * G::kSlot + G::kRawFloats) * 4 + wave * 1024);
+#pragma unroll
+        for (int j = 0; j < G::kUS; ++j)
+            if (j < G::kUS - 1 || wave < G::kUWaves) pwc::dma_b128_so(rs, base + j * kThreads * 16, u_off, j * u_step);
+    };
+    // VMEM operations of one group {raw(m + 1), U(m)} issued by THIS wave (wave-uniform; the counted waits need immediates)
+    const int n_grp = G::kRS - (wave < G::kRawWaves ? 0 : 1) + G::kUS - (wave < G::kUWaves ? 0 : 1);
+    constexpr int kN0 = G::kRS + G::kUS;
+    auto wait_groups1 = [&]() {                          // at most one group outstanding
+        if (n_grp == kN0) PWC_WAIT_VMCNT(kN0); else if (n_grp == kN0 - 1) PWC_WAIT_VMCNT(kN0 - 1); else PWC_WAIT_VMCNT(kN0 - 2);
+    };
+    auto wait_groups2 = [&]() {                          // at most two
+        if (n_grp == kN0) PWC_WAIT_VMCNT(2 * kN0); else if (n_grp == kN0 - 1) PWC_WAIT_VMCNT(2 * kN0 - 2); else PWC_WAIT_VMCNT(2 * kN0 - 4);
+    };
+
+    // this lane's patch inside a raw slot: channel kq, rows 4 tgi .. 4 tgi + 5, columns 4 n .. 4 n + 5
+    const int poff = kq * G::kPlane + (4 * tgi) * kRawW + 4 + 4 * n;
+    // this lane's U column inside a slot's U image: [g][k = kq][cout = 16 cbi + n][4]
+    const int uoff = G::kRawFloats + (kq * G::kCoutT + 16 * cbi + n) * 4;
+    constexpr int kUG = kCK * G::kCoutT * 4;              // floats per position group g
+
+    f32x4 acc[36];
+
+    // LDS reads through ONE opaque per-iteration base register + immediate offsets.  (Left to itself the compiler folds the ring slot
+    // into per-read constants beyond the 16-bit offset field and keeps a separate address register for every U group and patch row:
+    // ~10 registers and as many VALU operations per iteration.)
+    typedef const __attribute__((address_space(3))) f32x4 *lds4_t;
+    auto lds_read4 = [](unsigned base_bytes, int off_bytes) { return *reinterpret_cast<lds4_t>((uintptr_t)(base_bytes + off_bytes)); };
+    auto load_row = [&](unsigned base_bytes, int a, float (&d)[6]) {   // patch row a of this lane's channel / tile
+        const f32x4 v = lds_read4(base_bytes, a * kRawW * 4);
+        const f32x4 u = lds_read4(base_bytes, a * kRawW * 4 + 16);          // 16-byte reads are conflict-free here, 8-byte ones 2-way
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; d[4] = u[0]; d[5] = u[1];
+    };
+    const unsigned poff_b = lds0 + (unsigned)poff * 4u, uoff_b = lds0 + (unsigned)uoff * 4u;
+
+    float wA[6][6], wB[6][6];                 // row-transformed patches: w[a][j] = sum_b d[a][b] Bt[j][b]; ping-pong over chunks
+    float vE[6], vO[6];                       // V columns (six positions each): even / odd columns of the position grid
+    f32x4 ua7 = {0.f, 0.f, 0.f, 0.f}, ua8 = {0.f, 0.f, 0.f, 0.f};      // U groups 7, 8 (positions 28..35) carried into the next iteration
+#pragma unroll
+    for (int i = 0; i < 6; ++i) vO[i] = 0.f;  // "column 5 of chunk -1" adds 0 * 0
+
+    // One iteration = six phases of six MFMAs.  The iteration is ROTATED by one phase: it starts with column 5 of chunk k - 1, whose
+    // operands (U groups 7, 8 and the V column) were put into registers before the barrier, so the matrix pipe restarts right behind
+    // the barrier while the first U reads of chunk k are in flight; then columns 0..4 of chunk k.  Phase ph = 0..5 (0 = the rotated
+    // one) also makes V column ph of THIS chunk from w(k) (three parts in the shadows of its MFMAs 0..2) and the row transform of
+    // patch row ph of the NEXT chunk (three parts behind MFMAs 3..5; the row was read one phase earlier): exactly four VALU
+    // operations per MFMA.  U groups are read one phase ahead.
+    // Transform schedule, measured (tools/wino4_exp.sh, dc_conv1 / conv2_4): 2 = all 24 operations of a phase behind ONE MFMA 1806 / 491 us,
+    // 1 = two blocks of twelve 1823 / 497, 0 = four per MFMA 1921 / 519.  Evenly spread VALU work is the SLOWEST: with two waves per SIMD
+    // a wave in a long VALU burst leaves the matrix pipe to its partner, a wave that sprinkles VALU into every gap competes in every gap.
+#ifndef PWC_W4_BLOCK
+#define PWC_W4_BLOCK 2
+#endif
+    constexpr int kBlockSched = PWC_W4_BLOCK;
+    auto iteration = [&](int k, float (&wc)[6][6], float (&wn)[6][6]) {
+        // group G(k) = {raw(k+1), U(k)} has landed; G(k+1) = {raw(k+2), U(k+1)} may stay in flight.  (Past the last chunk the groups
+        // are zero-sized fetches and the patch rows read are zeros or stale data whose transforms nobody uses: no special cases.)
+        if (!(PWC_W4_EXP & 16)) {
+            wait_groups1();
+            __syncthreads();
+        }
+        unsigned uslot = uoff_b + (unsigned)__builtin_amdgcn_readfirstlane((k % 3) * G::kSlot * 4);
+        unsigned rnext = poff_b + (unsigned)__builtin_amdgcn_readfirstlane(((k + 1) % 3) * G::kSlot * 4);
+        asm volatile("" : "+v"(uslot), "+v"(rnext));            // opaque bases (see lds_read4)
+        f32x4 ua0, ua1, ua2, ua3, ua4, ua5, ua6;
+        float d0[6], d1[6];
+        auto ldu = [&](int g) { return lds_read4(uslot, g * kUG * 4); };
+#define PWC_W4_MFMA(P, UA, VB) acc[P] = __builtin_amdgcn_mfma_f32_16x16x4f32((UA)[(P) & 3], (VB), acc[P], 0, 0, 0)
+#pragma unroll
+        for (int ph = 0; ph < 6; ++ph) {
+            const int j = ph - 1;                               // column of chunk k this phase multiplies (ph 0: column 5 of chunk k - 1)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (ph == 0) {
+                    if (i < 2) PWC_W4_MFMA(30 + i, ua7, vO[i]); else PWC_W4_MFMA(30 + i, ua8, vO[i]);
+                } else {
+                    const int p = 6 * j + i, g = p >> 2;
+                    const f32x4 &ug_ = g == 0 ? ua0 : g == 1 ? ua1 : g == 2 ? ua2 : g == 3 ? ua3 : g == 4 ? ua4 : g == 5 ? ua5 : g == 6 ? ua6 : ua7;
+                    if (j & 1) PWC_W4_MFMA(p, ug_, vO[i]); else PWC_W4_MFMA(p, ug_, vE[i]);
+                }
+                // ---- in the shadow of this MFMA ----------------------------------------------------------------------
+                if (i == 0) {                                   // U groups of the next phase's column; patch row(s) of the next chunk
+                    if (ph == 0) { ua0 = ldu(0); ua1 = ldu(1); }
+                    if (ph == 1) ua2 = ldu(2);
+                    if (ph == 2) { ua3 = ldu(3); ua4 = ldu(4); }
+                    if (ph == 3) ua5 = ldu(5);
+                    if (ph == 4) { ua6 = ldu(6); ua7 = ldu(7); }
+                    if (ph == 5) ua8 = ldu(8);
+                    if (!(PWC_W4_EXP & 32)) {
+                        if (ph == 0) { load_row(rnext, 0, d0); load_row(rnext, 1, d1); }
+                        else if (ph < 5) load_row(rnext, ph + 1, ((ph + 1) & 1) ? d1 : d0);
+                    }
+                }
+                if (ph == 0 && i == 1 && !(PWC_W4_EXP & 4)) issue_raw(k + 3);
+                if (ph == 0 && i == 2 && !(PWC_W4_EXP & 4)) issue_u(k + 2);
+                {
+                    const float col[6] = {wc[0][ph], wc[1][ph], wc[2][ph], wc[3][ph], wc[4][ph], wc[5][ph]};
+                    float (&vdst)[6] = (ph & 1) ? vO : vE;
+                    float (&dsrc)[6] = (ph & 1) ? d1 : d0;
+                    if (kBlockSched == 2) {                     // all twenty-four operations of the phase behind MFMA 2
+                        if (i == 2) {
+                            bt6_part<0>(col, vdst); bt6_part<1>(col, vdst); bt6_part<2>(col, vdst);
+                            bt6_part<0>(dsrc, wn[ph]); bt6_part<1>(dsrc, wn[ph]); bt6_part<2>(dsrc, wn[ph]);
+                        }
+                    } else if (kBlockSched) {                   // twelve operations behind MFMA 2 (column) and MFMA 4 (row)
+                        if (i == 2) { bt6_part<0>(col, vdst); bt6_part<1>(col, vdst); bt6_part<2>(col, vdst); }
+                        if (i == 4) { bt6_part<0>(dsrc, wn[ph]); bt6_part<1>(dsrc, wn[ph]); bt6_part<2>(dsrc, wn[ph]); }
+                    } else if (i < 3) {                         // V column ph of this chunk, part i
+                        if (i == 0) bt6_part<0>(col, vdst); else if (i == 1) bt6_part<1>(col, vdst); else bt6_part<2>(col, vdst);
+                    } else {                                    // row transform of patch row ph of the next chunk, part i - 3
+                        if (i == 3) bt6_part<0>(dsrc, wn[ph]); else if (i == 4) bt6_part<1>(dsrc, wn[ph]); else bt6_part<2>(dsrc, wn[ph]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- prologue: raw(0) alone (its row transform precedes the loop), then the groups G(0) = {raw(1), U(0)}, G(1) = {raw(2), U(1)}
+    issue_raw(0);
+    issue_raw(1);
+    issue_u(0);
+    issue_raw(2);
+    issue_u(1);
+    wait_groups2();                                    // raw(0) has landed
+    __syncthreads();
+    {
+        float d[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            load_row(poff_b, a, d);
+            bt6(d, wA[a]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 36; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};       // (zeroed here: 144 registers less across the prologue)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched wave of each SIMD loses every issue arbitration otherwise
+
+    for (int k = 0; k < nchunks; k += 2) {             // two copies of the body: the w arrays ping-pong without register moves
+        iteration(k, wA, wB);
+        if (k + 1 < nchunks) iteration(k + 1, wB, wA);
+    }
+    // column 5 of the last chunk
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (i < 2) PWC_W4_MFMA(30 + i, ua7, vO[i]); else PWC_W4_MFMA(30 + i, ua8, vO[i]);
+    }
+#undef PWC_W4_MFMA
+
+    // ---- output transform At M A for this lane's 4 couts x 1 tile, bias, LeakyReLU, 16-byte stores ----------------
+    // (lane coordinates re-derived from the hardware lane id: keeping them alive across the loop cost two spilled registers, and a
+    // kernel that touches scratch at all pays for the scratch set-up of every workgroup)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int oyl = oy0 + 4 * tgi, ox = ox0 + 4 * (lane_e & 15);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int co = cb0 + 16 * cbi + 4 * (lane_e >> 4) + c;
+        float t[4][6];                                          // At applied along i (rows) for every column j
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float m[6] = {acc[6 * j + 0][c], acc[6 * j + 1][c], acc[6 * j + 2][c], acc[6 * j + 3][c], acc[6 * j + 4][c], acc[6 * j + 5][c]};
+            float o[4];
+            at6(m, o);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) t[pp][j] = o[pp];
+        }
+        const float bv = bias[min(co, Cout - 1)];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            float o[4];
+            at6(t[pp], o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o[q] += bv;
+                if (do_leaky) o[q] = leaky(o[q], slope);
+            }
+            const int oy = oyl + pp;
+            if (co < Cout && oy < H && ox < W)                   // W % 4 == 0: the four pixels are inside together
+                *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + (int64_t)co * plane + (int64_t)oy * W + ox) = (f32x4){o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
+inline int cout_padded4(int Cout) { return (Cout + 31) / 32 * 32; }
+
+template <int CB, int TG>
+int launch_wino4(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout,
+                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups) {
+    using G = Geo4<CB, TG>;
+    static pwc::LdsAttrOnce once;
+    if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino4_kernel<CB, TG>), G::kSmemBytes,
+                                            "conv3x3_wino4_kernel"))
+        return rc;
+    const int CoutP = cout_padded4(Cout);
+    const int tiles_x = (W + kGW - 1) / kGW, tiles_y = (H + 4 * TG - 1) / (4 * TG);
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
+    hipLaunchKernelGGL((conv3x3_wino4_kernel<CB, TG>), dim3((unsigned)nblk, (unsigned)ngroups), dim3(kThreads), G::kSmemBytes, st,
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0);
+    pwc::note_kernel("conv3x3_wino4_kernel", CB, TG, 1, 1, 1, 0);
+    return pwc::check_launch("conv3x3_wino4_kernel");
+}
+
+}  // namespace
+
+// Can this layer run here at all?  Dilation 1 (a dilated layer's lattices are not contiguous in memory: no 16-byte pieces),
+// W % 4 == 0 (aligned 16-byte row pieces and stores).
+static bool wino4_supported(int W, int dilation) { return dilation == 1 && W % 4 == 0; }
+
+// Does F(4x4,3x3) beat F(2x2,3x3) (pwc_conv3x3_wino_fwd) for this layer?  Rule measured at batch 16 (profiles/r03_wino4_layers.txt):
+// the tile groups are 8 or 16 rows x 64 columns, so the map must fill them, and the launch must cover the chip several times
+// over (a workgroup costs ~10 us outside its K loop).  PWC_CONV_WINO4=0 switches the route off (A/B runs; read once).
+extern "C" int pwc_conv3x3_wino4_preferred(int B, int Cin, int H, int W, int Cout, int dilation) {
+    if (B <= 0 || Cin < 32 || H <= 0 || W <= 0 || Cout < 32 || !wino4_supported(W, dilation)) return 0;
+    static const int knob = [] { const char *e = getenv("PWC_CONV_WINO4"); return (e && *e) ? atoi(e) : 1; }();
+    if (!knob) return 0;
+    const int n32 = cout_padded4(Cout) / 32;
+    const int tiles_x = (W + kGW - 1) / kGW;
+    // every launch the layer splits into must cover the chip: the 64-cout launch (8-row tile groups) and, for an odd number of
+    // 32-cout blocks, the 32-cout one (16-row groups) -- conv3_2 (96 couts @56x128) fails on the latter (128 workgroups, x0.94)
+    if (n32 >= 2) {
+        const int ty = (H + 7) / 8;
+        if ((double)H / (ty * 8) < 0.85 || (int64_t)B * tiles_x * ty * (n32 / 2) < 200) return 0;
+    }
+    if (n32 & 1) {
+        const int ty = (H + 15) / 16;
+        if ((double)H / (ty * 16) < 0.85 || (int64_t)B * tiles_x * ty < 200) return 0;
+    }
+    return (double)W / (tiles_x * kGW) >= 0.85;
+}
+
+extern "C" int64_t pwc_conv3x3_wino4_packed_bytes(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return -1;
+    return (int64_t)((Cin + kCK - 1) / kCK) * 36 * kCK * cout_padded4(Cout) * (int64_t)sizeof(float);
+}
+
+extern "C" int pwc_conv3x3_wino4_pack(const void *w, void *up, int Cin, int Cout, void *stream) {
+    if (!w || !up) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_pack: null pointer");
+    if (Cin <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_pack: bad shape");
+    if (!pwc::aligned16(up)) PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino4_pack: packed buffer must be 16-byte aligned");
+    const int64_t total = pwc_conv3x3_wino4_packed_bytes(Cin, Cout) / (int64_t)sizeof(float);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(w), static_cast<float *>(up), Cin, Cout, cout_padded4(Cout), total);
+    return pwc::check_launch("wino4_pack_kernel");
+}
+
+extern "C" int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *bias, void *y, int B, int Cin, int H, int W, int Cout,
+                                     int dilation, unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
+    if (!x || !up || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: null pointer");
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: bad shape");
+    if (!wino4_supported(W, dilation))
+        PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv3x3_wino4_fwd: needs dilation 1 and W %% 4 == 0 (got dilation %d, W %d): use pwc_conv3x3_wino_fwd", dilation, W);
+    if (!pwc::aligned16(up) || !pwc::aligned16(x) || !pwc::aligned16(y) || (x_bstride % 4) || (y_bstride % 4))
+        PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino4_fwd: tensors must be 16-byte aligned with batch strides that are multiples of 4");
+    const int64_t plane = (int64_t)H * W;
+    if (x_bstride < Cin * plane || y_bstride < Cout * plane) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: batch stride smaller than the tensor");
+    if (plane * kCK * 4 >= 0x7fffffffLL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv3x3_wino4_fwd: image plane too large for 32-bit DMA offsets");
+    const float *xf = static_cast<const float *>(x), *uf = static_cast<const float *>(up), *bf = static_cast<const float *>(bias);
+    float *yf = static_cast<float *>(y);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
+    const int n32 = cout_padded4(Cout) / 32;
+    // 64-cout workgroups (4 cout blocks x 2 tile groups) for as many pairs of 32 as there are, one 32-cout launch (2 x 4) for an odd rest
+    if (n32 >= 2)
+        if (const int rc = launch_wino4<4, 2>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2))
+            return rc;
+    if (n32 & 1)
+        return launch_wino4<2, 4>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1);
+    return PWC_OK;
+}

@@ -133,8 +133,10 @@ class PwcPlan:
 
         self.packed: Dict[str, torch.Tensor] = {}
         self.wino_packed: Dict[str, torch.Tensor] = {}
+        self.wino4_packed: Dict[str, torch.Tensor] = {}        # F(4x4,3x3) banks, packed on first use by the layers the rule picks
         self.conv_macs = {"direct": 0, "executed": 0}
         self.wino = os.environ.get("PWC_CONV_WINO", "1") != "0" and dtype == torch.float32
+        self.wino4 = os.environ.get("PWC_CONV_WINO4", "1") != "0"          # 0: large layers stay on F(2x2,3x3) (A/B runs, error budget)
         self.workspace: Optional[torch.Tensor] = None
         if conv_backend == "hip":
             for key, t in self.p.items():
@@ -145,6 +147,29 @@ class PwcPlan:
                     # G g Gt for every layer the Winograd route could take (67 MB for the whole net): nothing is allocated later
                     if self.wino and t.shape[0] >= 32 and t.shape[1] >= 16:
                         self.wino_packed[key[:-len(".weight")]] = ops.pack_conv3x3_wino(t)
+            # F(4x4,3x3) banks for the layers the measured rule picks at THIS geometry (4x the filter bytes each): packed now, so that a
+            # run never allocates (the lazy path in _conv only serves callers that drive _conv with other shapes, e.g. bench probes)
+            if self.wino and self.wino4:
+                geo = []
+                for l in range(2, 7):
+                    for n in self.pyramid_names[l - 1][1:]:
+                        if n is not None:
+                            geo.append((n + ".0", self._slots(B), PYRAMID_CH[l], PYRAMID_CH[l], l))
+                for l in range(2 if trunk2 else 3, 7):
+                    cin = level_in_channels(l, self.nd)
+                    for i, co in enumerate(DENSE_OUT):
+                        geo.append(("conv%d_%d.0" % (l, i), B, cin, co, l))
+                        cin += co
+                if trunk2:
+                    cin = level_in_channels(2, self.nd) + DENSE_TOTAL
+                    for i, (co, dil) in enumerate(CONTEXT):
+                        if dil == 1:
+                            geo.append(("dc_conv%d.0" % (i + 1), B, cin, co, 2))
+                        cin = co
+                for key, b_, cin, co, l in geo:
+                    h, w = self.size[l]
+                    if key in self.wino_packed and ops.conv3x3_wino4_preferred(b_, cin, h, w, co):
+                        self.wino4_packed[key] = ops.pack_conv3x3_wino4(self.p[key + ".weight"])
             # one split-K scratch shared by every stride-1 conv of the decoder (they run back to back on one stream)
             need = 0
             for l in range(2 if trunk2 else 3, 7):
@@ -183,6 +208,14 @@ class PwcPlan:
         w, b = self.p[key + ".weight"], self.p[key + ".bias"]
         macs = x.shape[0] * w.shape[0] * w.shape[1] * 9 * ((x.shape[2] - 1) // stride + 1) * ((x.shape[3] - 1) // stride + 1)
         self.conv_macs["direct"] += macs                          # what the layer costs as a direct convolution
+        if (self.wino and self.wino4 and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and dilation == 1 and residual is None
+                and x.dtype == torch.float32 and ops.conv3x3_wino4_preferred(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0])):
+            # Winograd F(4x4,3x3): 4x fewer multiplications than the direct form for the large, well-filled layers (gated: DESIGN.md 4b)
+            if key not in self.wino4_packed:
+                self.wino4_packed[key] = ops.pack_conv3x3_wino4(w)      # first (eager, warm-up) run; a captured replay finds it packed
+            ops.conv3x3_wino4(x, self.wino4_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out)
+            self.conv_macs["executed"] += macs * 36 // 144
+            return
         if (self.wino and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and residual is None and x.dtype == torch.float32
                 and ops.conv3x3_wino_preferred(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0], dilation)):
             # Winograd F(2x2,3x3) on the matrix cores: 2.25x fewer MFMA passes for the same fp32 convolution
@@ -327,6 +360,7 @@ class PwcPlan:
         tot += sum(t.numel() * t.element_size() for t in self.ctx + ([self.flow_out] if self.flow_out is not None else []))
         tot += sum(t.numel() * t.element_size() for t in self.packed.values())
         tot += sum(t.numel() * t.element_size() for t in self.wino_packed.values())
+        tot += sum(t.numel() * t.element_size() for t in self.wino4_packed.values())
         if self.workspace is not None:
             tot += self.workspace.numel() * self.workspace.element_size()
         return tot

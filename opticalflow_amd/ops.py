@@ -331,6 +331,52 @@ def conv3x3_wino(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cou
     return out
 
 
+def conv3x3_wino4_preferred(B: int, cin: int, H: int, W: int, cout: int, dilation: int = 1) -> bool:
+    """Measured rule: does Winograd F(4x4,3x3) beat F(2x2,3x3) for this layer (large, well-filled maps, dilation 1)?"""
+    return bool(_lib.load().pwc_conv3x3_wino4_preferred(B, cin, H, W, cout, dilation))
+
+
+def pack_conv3x3_wino4(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] float32 device tensor -> G g Gt of F(4x4,3x3) in the kernel's LDS order (4x the filter bytes)."""
+    if not weight.is_cuda:
+        raise PwcHipError("weight is on %s: the HIP path needs device tensors" % weight.device)
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3) or weight.dtype != torch.float32:
+        raise ValueError("expected float32 [Cout,Cin,3,3], got %s %s" % (weight.dtype, tuple(weight.shape)))
+    lib = _lib.load()
+    cout, cin = weight.shape[:2]
+    up = torch.empty((lib.pwc_conv3x3_wino4_packed_bytes(cin, cout) // 4,), dtype=torch.float32, device=weight.device)
+    w = weight.contiguous()
+    with torch.cuda.device(w.device):
+        rc = lib.pwc_conv3x3_wino4_pack(w.data_ptr(), up.data_ptr(), cin, cout, _stream(w))
+    check(rc, "pwc_conv3x3_wino4_pack")
+    return up
+
+
+def conv3x3_wino4(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cout: int, leaky_slope: Optional[float] = 0.1,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 / stride 1 / padding 1 convolution + bias (+ LeakyReLU) by Winograd F(4x4,3x3) on the matrix cores (fp32; W % 4 == 0)."""
+    lib = _lib.load()
+    bsx = _plane_dense(x, "x")
+    B, cin, H, W = x.shape
+    if x.dtype != torch.float32:
+        raise ValueError("conv3x3_wino4 is fp32 only")
+    if out is None:
+        out = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (B, cout, H, W) or out.dtype != x.dtype or out.device != x.device:
+        raise ValueError("out must be %s, got %s" % ((B, cout, H, W), tuple(out.shape)))
+    bsy = _plane_dense(out, "out")
+    need = lib.pwc_conv3x3_wino4_packed_bytes(cin, cout)
+    if upacked.dtype != torch.float32 or upacked.numel() * 4 != need or upacked.device != x.device:
+        raise ValueError("packed F(4x4,3x3) filters do not match Cin=%d Cout=%d (have %d B, need %d B)" % (cin, cout, upacked.numel() * 4, need))
+    if bias.dtype != torch.float32 or bias.numel() != cout or bias.device != x.device or not bias.is_contiguous():
+        raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
+    with torch.cuda.device(x.device):
+        rc = lib.pwc_conv3x3_wino4_fwd(x.data_ptr(), upacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout, 1,
+                                       FLAG_ACT_LEAKY if leaky_slope is not None else 0, float(leaky_slope or 0.0), bsx, bsy, _stream(x))
+    check(rc, "pwc_conv3x3_wino4_fwd")
+    return out
+
+
 def conv3x3_workspace_bytes(B: int, cin: int, H: int, W: int, cout: int, stride: int = 1, dilation: int = 1) -> int:
     """Scratch bytes the split-K route of this layer wants (0 = it never splits)."""
     n = _lib.load().pwc_conv2d_workspace_bytes(B, cin, H, W, cout, stride, dilation)

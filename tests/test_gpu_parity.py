@@ -902,3 +902,132 @@ def test_conv3x3_baseline_shapes_vs_fp64(gpu_device, layer):
         assert err <= tol, (name, i, err)
     if out_off is not None and out_off > 0:                       # the slice below the output was not touched
         assert bool(torch.isfinite(arena[:, :out_off]).all())
+
+
+# ---- Winograd F(4x4,3x3) route (pwc_conv3x3_wino4_fwd, round 3): gated by an error budget ------------------------------------------
+WINO4_CASES = [  # B, Cin, Cout, H, W
+    (1, 4, 32, 8, 64),         # one workgroup of each kind, one chunk
+    (2, 5, 7, 9, 12),          # ragged everything: Cin % 4, Cout < 16, H % 4, one partial tile column
+    (1, 16, 128, 12, 64),      # two 64-cout workgroups
+    (2, 37, 96, 17, 72),       # 64 + 32 couts (both kernel configurations), ragged chunk, ragged rows
+    (1, 64, 64, 20, 40),
+    (1, 130, 128, 16, 36),     # long K, ragged tile group
+    (3, 21, 40, 33, 132),      # CoutP = 64 with 24 padded couts, three column groups
+    (1, 565, 128, 24, 64),     # dc_conv1's channel counts
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_conv3x3_winograd4_vs_fp64(gpu_device, case):
+    """Same operator as conv3x3 / conv3x3_wino (nn.Conv2d 3x3 pad 1 + LeakyReLU, PWCNet.py:26-33) by F(4x4,3x3).  Error budget
+    (DESIGN.md 4b): per element within 1e-6 * sqrt(9 Cin) of an fp64 convolution on unit-scale data -- a third of the bound the
+    other fp32 kernels are held to, ~5x what F(2x2) measures -- and within 8.1e-5 of the F(2x2) result (VERDICT r2 item 7's gate:
+    3x the 2.7e-5 that F(2x2) differs from the direct kernel on dc_conv1)."""
+    from opticalflow_amd import ops
+    B, cin, cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1)
+    xd, wd, bd = x.to(gpu_device), w.to(gpu_device), b.to(gpu_device)
+    got = ops.conv3x3_wino4(xd, ops.pack_conv3x3_wino4(wd), bd, cout).cpu()
+    err = (got.double() - ref).abs().max().item()
+    f2 = ops.conv3x3_wino(xd, ops.pack_conv3x3_wino(wd), bd, cout).cpu()
+    print("F(4x4) %s: max err vs fp64 %.2e (budget %.2e), vs F(2x2) %.2e" % (case, err, 1e-6 * (cin * 9) ** 0.5, (got - f2).abs().max().item()))
+    assert err <= 1e-6 * (cin * 9) ** 0.5
+    assert (got - f2).abs().max().item() <= 8.1e-5
+    lin = ops.conv3x3_wino4(xd, ops.pack_conv3x3_wino4(wd), bd, cout, leaky_slope=None).cpu()
+    assert (lin.double() - F.conv2d(x.double(), w.double(), b.double(), padding=1)).abs().max().item() <= 1e-6 * (cin * 9) ** 0.5
+
+
+@pytest.mark.gpu
+def test_conv3x3_winograd4_arena_views_rule_and_errors(gpu_device):
+    """Channel-slice views of a wider arena on both sides, as the decoder uses them; the measured rule; unsupported geometry is an
+    error of the ABI, not a silent fallback."""
+    from opticalflow_amd import ops
+    from opticalflow_amd._lib import PwcHipError
+    g = torch.Generator().manual_seed(6)
+    arena = torch.randn(2, 72, 16, 64, generator=g).to(gpu_device)
+    w = (torch.randn(32, 40, 3, 3, generator=g) * 0.05).to(gpu_device)
+    b = torch.randn(32, generator=g).to(gpu_device) * 0.1
+    x = arena[:, 32:72]
+    out = arena[:, 0:32]
+    ref = F.leaky_relu(F.conv2d(x.contiguous().cpu().double(), w.cpu().double(), b.cpu().double(), padding=1), 0.1)
+    keep = arena[:, 32:].clone()
+    ops.conv3x3_wino4(x, ops.pack_conv3x3_wino4(w), b, 32, out=out)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-6 * (40 * 9) ** 0.5
+    assert torch.equal(arena[:, 32:], keep)                                   # the input slice next to the output was not touched
+    with pytest.raises(ValueError):
+        ops.conv3x3_wino4(x, ops.pack_conv3x3_wino4(w)[:-4], b, 32)
+    with pytest.raises(PwcHipError):                                          # W % 4 != 0 has no 16-byte row pieces
+        ops.conv3x3_wino4(torch.zeros(1, 40, 8, 30, device=gpu_device), ops.pack_conv3x3_wino4(w), b, 32)
+    pref = ops.conv3x3_wino4_preferred
+    assert pref(16, 565, 112, 256, 128) and pref(16, 533, 112, 256, 32) and pref(16, 373, 112, 256, 96) and pref(16, 277, 56, 128, 128)
+    assert not pref(16, 405, 56, 128, 96) and not pref(16, 565, 56, 128, 32)     # their 32-cout launch would be 128 workgroups
+    assert not pref(16, 533, 28, 64, 64) and not pref(16, 128, 112, 256, 128, 2) and not pref(16, 16, 224, 512, 16)
+
+
+@pytest.mark.gpu
+def test_conv3x3_winograd4_baseline_shapes_vs_fp64(gpu_device):
+    """dc_conv1 (565->128) and conv2_2 (373->96: a 64-cout and a 32-cout launch) at 16 x 112 x 256 exactly as the plan launches
+    them (arena views), items 0 and 15 against fp64 conv2d; the kernel the library launched is read back."""
+    from opticalflow_amd import ops, _lib
+    B, H, W = 16, 112, 256
+    for name, cin, cout, in_off, out_off in (("dc_conv1", 565, 128, 0, None), ("conv2_2", 373, 96, 192, 96)):
+        gen = torch.Generator(device=gpu_device).manual_seed(2000 + cin)
+        arena = torch.randn(B, 565, H, W, generator=gen, device=gpu_device)
+        g = torch.Generator().manual_seed(cin * 3 + cout)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        x = arena[:, in_off:in_off + cin]
+        out = torch.empty(B, cout, H, W, device=gpu_device) if out_off is None else arena[:, out_off:out_off + cout]
+        xi = {i: x[i:i + 1].cpu().double() for i in (0, B - 1)}
+        assert ops.conv3x3_wino4_preferred(B, cin, H, W, cout)
+        ops.conv3x3_wino4(x, ops.pack_conv3x3_wino4(w.to(gpu_device)), b.to(gpu_device), cout, out=out)
+        kern = _lib.load().pwc_last_conv_kernel().decode()
+        assert "wino4" in kern, kern
+        torch.set_num_threads(max(8, torch.get_num_threads()))
+        for i, xd in xi.items():
+            ref = F.leaky_relu(F.conv2d(xd, w.double(), b.double(), padding=1), 0.1)
+            err = (out[i:i + 1].cpu().double() - ref).abs().max().item()
+            print("%s item %d: %s max err %.2e (budget %.2e)" % (name, i, kern, err, 1e-6 * (cin * 9) ** 0.5))
+            assert err <= 1e-6 * (cin * 9) ** 0.5
+
+
+@pytest.mark.gpu
+def test_forward_winograd4_error_budget(gpu_device, monkeypatch):
+    """Whole-forward gate of the F(4x4) route on the benchmark workload, 16 x 6 x 448 x 1024 -- where the rule sends
+    twelve level-2 / level-3 / pyramid / context layers to F(4x4): EPE of items 0 and 15 against the CPU oracle below 1e-4, the whole
+    batch within 5e-5 of the same forward with the route switched off (PWC_CONV_WINO4=0: F(2x2) everywhere), fewer executed
+    multiplications with it, bit-repeatable."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    xc = torch.rand(16, 6, 448, 1024, generator=torch.Generator().manual_seed(1234))
+    x = xc.to(gpu_device)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PWC_CONV_WINO4", flag)
+        net = PWCDCNet()
+        sd = synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02)
+        net.load_state_dict(sd)
+        net = net.to(gpu_device).eval()
+        f = net(x).clone()
+        assert torch.equal(net(x), f)
+        plan = net._plan_for(x)
+        res[flag] = (f.cpu(), plan.conv_macs["executed"], sorted(plan.wino4_packed))
+        print("forward 16x448x1024, F(4x4) route %s: %.2f GMAC executed per pair, %d layers on F(4x4) %s"
+              % ("on" if flag == "1" else "off", plan.conv_macs["executed"] / 16e9, len(plan.wino4_packed), sorted(plan.wino4_packed)))
+    assert len(res["1"][2]) >= 10 and not res["0"][2] and res["1"][1] < 0.85 * res["0"][1]
+    assert {"dc_conv1.0", "conv2_1.0", "conv2_2.0", "conv2_4.0", "conv3_1.0"} <= set(res["1"][2]) and "conv3_2.0" not in res["1"][2]
+    d = O.epe(res["1"][0], res["0"][0])
+    print("F(4x4) vs F(2x2) forward: EPE %.3e" % d)
+    assert d < 5e-5
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    for i in (0, 15):
+        with torch.no_grad():
+            ref = O.pwc_forward(sd, xc[i:i + 1])
+        e4, e2 = O.epe(res["1"][0][i:i + 1], ref), O.epe(res["0"][0][i:i + 1], ref)
+        print("item %d vs CPU oracle: F(4x4) route EPE %.3e, F(2x2) route %.3e" % (i, e4, e2))
+        assert e4 < 1e-4 and e2 < 1e-4
