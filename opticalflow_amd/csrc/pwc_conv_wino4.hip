@@ -174,7 +174,7 @@ template <int CB, int TG>
 __global__ void __launch_bounds__(kThreads, 1)
 conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0) {
+                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups) {
     using G = Geo4<CB, TG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 3 x [raw | U]
 
@@ -185,13 +185,26 @@ conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     const int kq = lane >> 4;                 // channel of the chunk (A / B k index); D rows 4 kq .. 4 kq + 3
     const int cbi = wave % CB, tgi = wave / CB;
 
-    int bid = blockIdx.x;
-    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous runs of tiles
+    // One-dimensional grid of nblk tiles x ngroups cout groups.  Workgroups i, i+8, ... share an XCD: each XCD gets a contiguous run of
+    // tiles (halo re-reads hit its L2) and runs the cout groups of one tile BACK TO BACK, so that the second group finds the input
+    // tile in that L2 instead of fetching it again (PMC: 2.17x -> 1.4x the algorithmic bytes on dc_conv1).
+    int bid, grp;
+    {
+        const int id = (int)blockIdx.x;
+        if ((nblk & 7) == 0) {
+            const int slot = id >> 3;
+            grp = slot % ngroups;
+            bid = (id & 7) * (nblk >> 3) + slot / ngroups;
+        } else {
+            grp = id / nblk;
+            bid = id % nblk;
+        }
+    }
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int cb0 = co0 + (int)blockIdx.y * G::kCoutT;
+    const int cb0 = co0 + grp * G::kCoutT;
     const int ox0 = tx * kGW;
     const int oy0 = ty * (4 * TG);
     const int plane = H * W;
@@ -434,9 +447,9 @@ int launch_wino4(const float *x, const float *up, const float *bias, float *y, i
     const int CoutP = cout_padded4(Cout);
     const int tiles_x = (W + kGW - 1) / kGW, tiles_y = (H + 4 * TG - 1) / (4 * TG);
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
-    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
-    hipLaunchKernelGGL((conv3x3_wino4_kernel<CB, TG>), dim3((unsigned)nblk, (unsigned)ngroups), dim3(kThreads), G::kSmemBytes, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0);
+    if (nblk * ngroups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
+    hipLaunchKernelGGL((conv3x3_wino4_kernel<CB, TG>), dim3((unsigned)(nblk * ngroups)), dim3(kThreads), G::kSmemBytes, st,
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, (int)nblk, ngroups);
     pwc::note_kernel("conv3x3_wino4_kernel", CB, TG, 1, 1, 1, 0);
     return pwc::check_launch("conv3x3_wino4_kernel");
 }

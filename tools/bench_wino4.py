@@ -40,6 +40,20 @@ if mode in ("check", "all"):
     case(1, 12, 32, 10, 36, leaky=None)
 
 
+if mode == "pmc":          # one layer, few launches, for the profiler passes (tools/collect_profiles_r03.sh): dc_conv1 at batch 16
+    B, H, W, cin, cout = 16, 112, 256, 565, 128
+    x = torch.randn(B, cin, H, W, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.zeros(cout, device=dev)
+    u4, u2 = ops.pack_conv3x3_wino4(w), ops.pack_conv3x3_wino(w)
+    y = torch.empty(B, cout, H, W, device=dev)
+    for _ in range(40):        # F(2x2) first: ~90 ms that bring the clocks up (a different kernel name in the trace)
+        ops.conv3x3_wino(x, u2, b, cout, out=y)
+    for _ in range(30):        # back to back, as in the forward's steady state: the profiler's average is over these
+        ops.conv3x3_wino4(x, u4, b, cout, out=y)
+    torch.cuda.synchronize()
+
+
 def t(fn, reps=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):

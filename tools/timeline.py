@@ -24,7 +24,10 @@ def short(n):
     m = (re.search(r"conv3x3_f16w8_kernel<(\d+), (\d+)", n) or re.search(r"conv3x3_f16w8_kernelILi(\d+)ELi(\d+)E", n))
     if m:
         return "f16w8<MT%s,D%s>" % m.groups()
-    m = re.search(r"conv3x3_wino(8?)_kernel<(\d+)>", n) or re.search(r"conv3x3_wino(8?)_kernelILi(\d+)E", n)
+    m = re.search(r"conv3x3_wino4_kernel<(\d+), (\d+)>", n) or re.search(r"conv3x3_wino4_kernelILi(\d+)ELi(\d+)E", n)
+    if m:
+        return "wino4<CB%s,TG%s>" % m.groups()
+    m = re.search(r"conv3x3_wino(8r?)_kernel<(\d+)>", n) or re.search(r"conv3x3_wino(8r?)_kernelILi(\d+)E", n)
     if m:
         return "wino%s<MT%s>" % m.groups()
     m = re.search(r"stream3x3_kernel<(\d+), (\d+), (\d+)>", n)
@@ -32,7 +35,7 @@ def short(n):
         return "stream3x3<mode%s,TH%s,KS%s>" % m.groups()
     if "corr81_dma_kernel<true>" in n or "corr81_dma_kernelILb1E" in n:
         return "warp+corr81"
-    for k in ("pyr1_fused", "corr81_bwd", "corr81_c8", "warp_c8", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
+    for k in ("pyr1_fused", "corr81_bwd", "corr81_c8", "warp_c8", "nchw_to_c8_hilo", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
         if k in n:
             return k
     for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "splitk_reduce", "warp_kernel", "copyBuffer", "elementwise", "pack3x3"):
