@@ -140,8 +140,10 @@ def probes_fp32(result, args, plan, B, H, W, h2, w2, stream):
     if args.conv_backend == "hip":
         cin = plan.arena[2].shape[1]
         direct_flops = 2.0 * 128 * cin * 9 * h2 * w2 * B
-        ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], plan.ctx[0], dilation=1), PROBE_REPS, stream)
+        probe_out = torch.empty((B, 128, h2, w2), device=plan.arena[2].device)       # (the plan's own ctx[0] may be in lattice-major layout)
+        ms = event_time_ms(lambda: plan._conv("dc_conv1", plan.arena[2], probe_out, dilation=1), PROBE_REPS, stream)
         kern = last_conv_kernel()
+        del probe_out
         wino, wino4 = "wino" in kern, "wino4" in kern
         # The roofline that bounds the kernel counts the multiplications it EXECUTES: Winograd F(2x2,3x3) does 16 per 2x2 outputs,
         # F(4x4,3x3) 36 per 4x4 outputs (instead of 36 / 144 for the direct form), per REAL input channel (the zero channels that pad

@@ -52,6 +52,10 @@ extern "C" {
                                  multiplying by corr_multiply (correlation.py:35-36)              */
 #define PWC_ACT_LEAKY 2u      /* fuse LeakyReLU(slope) into the epilogue (PWCNet.py:72,199)          */
 #define PWC_CONV_RESIDUAL 4u  /* y += residual (flow2 + dc_conv7(...), PWCNet.py:268)                */
+/* pwc_conv3x3_wino4_fwd only */
+#define PWC_CONV_SPLIT2 32u   /* y is [4B][Cout][H/2][W/2] (y_bstride = its image stride): image b is written as its four pixel lattices
+                                 4b + 2 (oy & 1) + (ox & 1), so that the next, twice-as-dilated layer of the context network runs as
+                                 a dilation-1 convolution on 4B small images; pwc_lattice_unsplit_f32 brings a tensor back */
 /* pwc_conv2d_f16_fwd only */
 #define PWC_CONV_OUT_F32 8u   /* y is float [B][ceil(Cout/8)][Ho][Wo][8] instead of half (flow heads: the values that
                                  carry the flow from level to level stay in fp32)                    */
@@ -180,6 +184,9 @@ int pwc_conv3x3_wino4_pack(const void *w, void *up, int Cin, int Cout, void *str
 int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *bias, void *y,
                           int B, int Cin, int H, int W, int Cout, int dilation, unsigned flags, float leaky_slope,
                           int64_t x_bstride, int64_t y_bstride, void *stream);
+/* Inverse of `levels` nested PWC_CONV_SPLIT2 stores: x [B * 4^levels][C][h][w] (contiguous) -> y [B][C][h << levels][w << levels]
+ * (dense planes, free batch stride); image index ((b*4 + s1)*4 + s2)... with s_i = 2 (y_i & 1) + (x_i & 1), coarsest split first. */
+int pwc_lattice_unsplit_f32(const void *x, void *y, int B, int C, int h, int w, int levels, int64_t y_bstride, void *stream);
 
 /* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------
  * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch

@@ -20,6 +20,7 @@ FLAG_ACT_LEAKY = 2
 FLAG_CONV_RESIDUAL = 4
 FLAG_CONV_OUT_F32 = 8
 FLAG_CONV_SPLIT_W = 16
+FLAG_CONV_SPLIT2 = 32
 
 # name -> (restype, argtypes); mirrors include/pwc_hip.h one to one
 SIGNATURES = {
@@ -59,6 +60,7 @@ SIGNATURES = {
     "pwc_conv3x3_wino4_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pwc_conv3x3_wino4_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
                                      c_int64, c_int64, c_void_p]),
+    "pwc_lattice_unsplit_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "pwc_conv2d_f16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),
     "pwc_nchw_to_c8_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),

@@ -174,7 +174,7 @@ template <int CB, int TG>
 __global__ void __launch_bounds__(kThreads, 1)
 conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups) {
+                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
     using G = Geo4<CB, TG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 3 x [raw | U]
 
@@ -428,17 +428,50 @@ conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, 
                 if (do_leaky) o[q] = leaky(o[q], slope);
             }
             const int oy = oyl + pp;
-            if (co < Cout && oy < H && ox < W)                   // W % 4 == 0: the four pixels are inside together
-                *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + (int64_t)co * plane + (int64_t)oy * W + ox) = (f32x4){o[0], o[1], o[2], o[3]};
+            if (co < Cout && oy < H && ox < W) {                 // W % 4 == 0: the four pixels are inside together
+                if (!split2) {
+                    *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + (int64_t)co * plane + (int64_t)oy * W + ox) = (f32x4){o[0], o[1], o[2], o[3]};
+                } else {
+                    // PWC_CONV_SPLIT2: image b is written as FOUR images 4b + 2 (oy & 1) + (ox & 1) of (H/2) x (W/2) -- the pixel
+                    // lattices of the next, twice-as-dilated layer, which then runs as a dilation-1 convolution on 4B small images
+                    float *d0 = y + ((int64_t)b * 4 + 2 * (oy & 1)) * bsy + (int64_t)co * (plane >> 2) + (int64_t)(oy >> 1) * (W >> 1) + (ox >> 1);
+                    *reinterpret_cast<f32x2 *>(d0) = (f32x2){o[0], o[2]};
+                    *reinterpret_cast<f32x2 *>(d0 + bsy) = (f32x2){o[1], o[3]};
+                }
+            }
         }
     }
+}
+
+// Inverse of L nested PWC_CONV_SPLIT2 stores (see pwc_hip.h): one thread per four output pixels of a row; the four come from four
+// different lattice images (or two, alternating, for L = 1), the store is 16 bytes.
+__global__ void __launch_bounds__(256)
+lattice_unsplit_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int h, int w, int L, int64_t bsy, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int W = w << L, H = h << L, W4 = W >> 2;
+    const int xq = (int)(idx % W4);
+    int64_t t = idx / W4;
+    const int yy = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int xx = 4 * xq + q;
+        int n = b;
+        for (int l = 0; l < L; ++l) n = n * 4 + 2 * ((yy >> l) & 1) + ((xx >> l) & 1);
+        v[q] = x[(((int64_t)n * C + c) * h + (yy >> L)) * w + (xx >> L)];
+    }
+    *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + ((int64_t)c * H + yy) * W + 4 * xq) = (f32x4){v[0], v[1], v[2], v[3]};
 }
 
 inline int cout_padded4(int Cout) { return (Cout + 31) / 32 * 32; }
 
 template <int CB, int TG>
 int launch_wino4(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout,
-                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups) {
+                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups, int split2) {
     using G = Geo4<CB, TG>;
     static pwc::LdsAttrOnce once;
     if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino4_kernel<CB, TG>), G::kSmemBytes,
@@ -449,7 +482,7 @@ int launch_wino4(const float *x, const float *up, const float *bias, float *y, i
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
     if (nblk * ngroups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
     hipLaunchKernelGGL((conv3x3_wino4_kernel<CB, TG>), dim3((unsigned)(nblk * ngroups)), dim3(kThreads), G::kSmemBytes, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, (int)nblk, ngroups);
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, (int)nblk, ngroups, split2);
     pwc::note_kernel("conv3x3_wino4_kernel", CB, TG, 1, 1, 1, 0);
     return pwc::check_launch("conv3x3_wino4_kernel");
 }
@@ -506,18 +539,34 @@ extern "C" int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *
     if (!pwc::aligned16(up) || !pwc::aligned16(x) || !pwc::aligned16(y) || (x_bstride % 4) || (y_bstride % 4))
         PWC_FAIL(PWC_EALIGN, "pwc_conv3x3_wino4_fwd: tensors must be 16-byte aligned with batch strides that are multiples of 4");
     const int64_t plane = (int64_t)H * W;
-    if (x_bstride < Cin * plane || y_bstride < Cout * plane) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: batch stride smaller than the tensor");
+    if (x_bstride < Cin * plane || y_bstride < Cout * plane / ((flags & PWC_CONV_SPLIT2) ? 4 : 1))
+        PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: batch stride smaller than the tensor");
     if (plane * kCK * 4 >= 0x7fffffffLL) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_conv3x3_wino4_fwd: image plane too large for 32-bit DMA offsets");
     const float *xf = static_cast<const float *>(x), *uf = static_cast<const float *>(up), *bf = static_cast<const float *>(bias);
     float *yf = static_cast<float *>(y);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
+    const int split2 = (flags & PWC_CONV_SPLIT2) ? 1 : 0;
+    if (split2 && ((H & 1) || (W & 7) || (y_bstride & 1)))
+        PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: PWC_CONV_SPLIT2 needs even H, W %% 8 == 0 and an even batch stride");
     const int n32 = cout_padded4(Cout) / 32;
     // 64-cout workgroups (4 cout blocks x 2 tile groups) for as many pairs of 32 as there are, one 32-cout launch (2 x 4) for an odd rest
     if (n32 >= 2)
-        if (const int rc = launch_wino4<4, 2>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2))
+        if (const int rc = launch_wino4<4, 2>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2))
             return rc;
     if (n32 & 1)
-        return launch_wino4<2, 4>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1);
+        return launch_wino4<2, 4>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2);
     return PWC_OK;
+}
+
+extern "C" int pwc_lattice_unsplit_f32(const void *x, void *y, int B, int C, int h, int w, int levels, int64_t y_bstride, void *stream) {
+    if (!x || !y || B <= 0 || C <= 0 || h <= 0 || w <= 0 || levels < 1 || levels > 4) PWC_FAIL(PWC_EINVAL, "pwc_lattice_unsplit_f32: bad argument");
+    const int64_t W = (int64_t)w << levels, H = (int64_t)h << levels;
+    if ((W & 3) || !pwc::aligned16(y) || (y_bstride & 3) || y_bstride < C * H * W)
+        PWC_FAIL(PWC_EALIGN, "pwc_lattice_unsplit_f32: the output needs 16-byte aligned rows (W %% 4 == 0) and a batch stride >= C*H*W");
+    const int64_t total = (int64_t)B * C * H * (W >> 2);
+    if ((total + 255) / 256 > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_lattice_unsplit_f32: grid too large");
+    hipLaunchKernelGGL(lattice_unsplit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(x), static_cast<float *>(y), C, h, w, levels, y_bstride, total);
+    return pwc::check_launch("lattice_unsplit_kernel");
 }

@@ -130,6 +130,24 @@ class PwcPlan:
         h2, w2 = self.size[2]
         self.flow_out = torch.empty((B, 2, h2, w2), **kw) if trunk2 else None
         self.ctx = [torch.empty((B, c, h2, w2), **kw) for c, _ in CONTEXT] if trunk2 else []
+        # Context network in LATTICE-MAJOR layout (round 3): dc_conv1..3 store their result as its four pixel lattices (PWC_CONV_SPLIT2),
+        # so the next layer -- dilation 2, 4, 8 in the reference (PWCNet.py:126-131) -- is a dilation-1 convolution on 4x as many
+        # images of half the size, with contiguous rows: F(4x4) / F(2x2) at their dilation-1 speed instead of strided lattice
+        # addressing (dc_conv2 611 -> ~430 us, dc_conv3 679 -> ~470 us at batch 16).  dc_conv5 (dilation 16) is a dilation-2
+        # convolution on the dilation-8 lattices; its 64-channel result is brought back to NCHW by pwc_lattice_unsplit_f32.
+        wino_on = os.environ.get("PWC_CONV_WINO", "1") != "0" and os.environ.get("PWC_CONV_WINO4", "1") != "0"
+        self.ctx_lattice = bool(
+            trunk2 and conv_backend == "hip" and dtype == torch.float32 and wino_on and os.environ.get("PWC_CTX_LATTICE", "1") != "0"
+            and h2 % 8 == 0 and w2 % 32 == 0
+            and ops.conv3x3_wino4_preferred(B, level_in_channels(2, self.nd) + DENSE_TOTAL, h2, w2, CONTEXT[0][0])
+            and ops.conv3x3_wino4_preferred(4 * B, CONTEXT[0][0], h2 // 2, w2 // 2, CONTEXT[1][0])
+            and ops.conv3x3_wino4_preferred(16 * B, CONTEXT[1][0], h2 // 4, w2 // 4, CONTEXT[2][0]))
+        if self.ctx_lattice:
+            self.ctx[0] = torch.empty((4 * B, CONTEXT[0][0], h2 // 2, w2 // 2), **kw)
+            self.ctx[1] = torch.empty((16 * B, CONTEXT[1][0], h2 // 4, w2 // 4), **kw)
+            self.ctx[2] = torch.empty((64 * B, CONTEXT[2][0], h2 // 8, w2 // 8), **kw)
+            self.ctx[3] = torch.empty((64 * B, CONTEXT[3][0], h2 // 8, w2 // 8), **kw)
+            self.ctx4_lat = torch.empty((64 * B, CONTEXT[4][0], h2 // 8, w2 // 8), **kw)
 
         self.packed: Dict[str, torch.Tensor] = {}
         self.wino_packed: Dict[str, torch.Tensor] = {}
@@ -166,6 +184,9 @@ class PwcPlan:
                         if dil == 1:
                             geo.append(("dc_conv%d.0" % (i + 1), B, cin, co, 2))
                         cin = co
+                    if self.ctx_lattice:                      # dc_conv2 / dc_conv3 run as dilation-1 layers on the lattices
+                        for key in ("dc_conv2.0", "dc_conv3.0"):
+                            self.wino4_packed[key] = ops.pack_conv3x3_wino4(self.p[key + ".weight"])
                 for key, b_, cin, co, l in geo:
                     h, w = self.size[l]
                     if key in self.wino_packed and ops.conv3x3_wino4_preferred(b_, cin, h, w, co):
@@ -342,11 +363,36 @@ class PwcPlan:
 
     def _context(self) -> torch.Tensor:
         """Context network + residual (PWCNet.py:267-268)."""
+        if self.ctx_lattice:
+            return self._context_lattice()
         t = self.arena[2]
         for i, (_, dil) in enumerate(CONTEXT):
             self._conv("dc_conv%d" % (i + 1), t, self.ctx[i], dilation=dil)
             t = self.ctx[i]
         self._conv("dc_conv7", t, self.flow_out, act=False, residual=self.flow[2])
+        return self.flow_out
+
+    def _context_lattice(self) -> torch.Tensor:
+        """The same seven layers with dc_conv1..5 in lattice-major layout (see __init__): every layer is the reference's layer on the
+        same values, only the order in which pixels are stored between them differs."""
+        B = self.B
+
+        def w4(name, x, out, split2):
+            key = name + ".0"
+            w, b = self.p[key + ".weight"], self.p[key + ".bias"]
+            macs = x.shape[0] * w.shape[0] * w.shape[1] * 9 * x.shape[2] * x.shape[3]
+            self.conv_macs["direct"] += macs
+            self.conv_macs["executed"] += macs * 36 // 144
+            ops.conv3x3_wino4(x, self.wino4_packed[key], b, w.shape[0], leaky_slope=LEAKY, out=out, split2=split2)
+
+        w4("dc_conv1", self.arena[2], self.ctx[0], True)          # [B,565,H,W]      -> 4B  x [128,H/2,W/2]   (lattices of dilation 2)
+        w4("dc_conv2", self.ctx[0], self.ctx[1], True)            # dilation 2 = 1 on those -> 16B x [128,H/4,W/4]
+        w4("dc_conv3", self.ctx[1], self.ctx[2], True)            # dilation 4 = 1          -> 64B x [128,H/8,W/8]
+        self._conv("dc_conv4", self.ctx[2], self.ctx[3], dilation=1)        # dilation 8 = 1 on the dilation-8 lattices
+        self._conv("dc_conv5", self.ctx[3], self.ctx4_lat, dilation=2)      # dilation 16 = 2 on them
+        ops.lattice_unsplit(self.ctx4_lat, B, 3, out=self.ctx[4])
+        self._conv("dc_conv6", self.ctx[4], self.ctx[5], dilation=1)
+        self._conv("dc_conv7", self.ctx[5], self.flow_out, act=False, residual=self.flow[2])
         return self.flow_out
 
     def flows(self) -> Tuple[torch.Tensor, ...]:
@@ -358,6 +404,8 @@ class PwcPlan:
         for group in (self.pyr_a, self.pyr_b, self.warped, self.arena, self.flow):
             tot += sum(t.numel() * t.element_size() for t in group.values())
         tot += sum(t.numel() * t.element_size() for t in self.ctx + ([self.flow_out] if self.flow_out is not None else []))
+        if getattr(self, "ctx_lattice", False):
+            tot += self.ctx4_lat.numel() * self.ctx4_lat.element_size()
         tot += sum(t.numel() * t.element_size() for t in self.packed.values())
         tot += sum(t.numel() * t.element_size() for t in self.wino_packed.values())
         tot += sum(t.numel() * t.element_size() for t in self.wino4_packed.values())

@@ -353,17 +353,22 @@ def pack_conv3x3_wino4(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_wino4(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cout: int, leaky_slope: Optional[float] = 0.1,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """3x3 / stride 1 / padding 1 convolution + bias (+ LeakyReLU) by Winograd F(4x4,3x3) on the matrix cores (fp32; W % 4 == 0)."""
+                  out: Optional[torch.Tensor] = None, split2: bool = False) -> torch.Tensor:
+    """3x3 / stride 1 / padding 1 convolution + bias (+ LeakyReLU) by Winograd F(4x4,3x3) on the matrix cores (fp32; W % 4 == 0).
+    split2: the result is stored as its four pixel lattices, [4B, cout, H/2, W/2] with image 4b + 2(y & 1) + (x & 1) -- the input
+    layout in which the next, twice-as-dilated layer is a dilation-1 convolution (lattice_unsplit is the inverse)."""
     lib = _lib.load()
     bsx = _plane_dense(x, "x")
     B, cin, H, W = x.shape
     if x.dtype != torch.float32:
         raise ValueError("conv3x3_wino4 is fp32 only")
+    oshape = (4 * B, cout, H // 2, W // 2) if split2 else (B, cout, H, W)
+    if split2 and (H % 2 or W % 8):
+        raise ValueError("split2 needs even H and W % 8 == 0")
     if out is None:
-        out = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device)
-    elif tuple(out.shape) != (B, cout, H, W) or out.dtype != x.dtype or out.device != x.device:
-        raise ValueError("out must be %s, got %s" % ((B, cout, H, W), tuple(out.shape)))
+        out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != oshape or out.dtype != x.dtype or out.device != x.device:
+        raise ValueError("out must be %s, got %s" % (oshape, tuple(out.shape)))
     bsy = _plane_dense(out, "out")
     need = lib.pwc_conv3x3_wino4_packed_bytes(cin, cout)
     if upacked.dtype != torch.float32 or upacked.numel() * 4 != need or upacked.device != x.device:
@@ -372,8 +377,26 @@ def conv3x3_wino4(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, co
         raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
     with torch.cuda.device(x.device):
         rc = lib.pwc_conv3x3_wino4_fwd(x.data_ptr(), upacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout, 1,
-                                       FLAG_ACT_LEAKY if leaky_slope is not None else 0, float(leaky_slope or 0.0), bsx, bsy, _stream(x))
+                                       (FLAG_ACT_LEAKY if leaky_slope is not None else 0) | (_lib.FLAG_CONV_SPLIT2 if split2 else 0),
+                                       float(leaky_slope or 0.0), bsx, bsy, _stream(x))
     check(rc, "pwc_conv3x3_wino4_fwd")
+    return out
+
+
+def lattice_unsplit(x: torch.Tensor, batch: int, levels: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inverse of `levels` nested split2 stores: [batch * 4**levels, C, h, w] (contiguous) -> [batch, C, h << levels, w << levels]."""
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4 or x.shape[0] != batch * 4 ** levels:
+        raise ValueError("x must be a contiguous float32 device tensor [batch * 4**levels, C, h, w]")
+    _, C, h, w = x.shape
+    oshape = (batch, C, h << levels, w << levels)
+    if out is None:
+        out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != oshape or out.dtype != x.dtype or out.device != x.device:
+        raise ValueError("out must be %s, got %s" % (oshape, tuple(out.shape)))
+    bsy = _plane_dense(out, "out")
+    with torch.cuda.device(x.device):
+        rc = _lib.load().pwc_lattice_unsplit_f32(x.data_ptr(), out.data_ptr(), batch, C, h, w, levels, bsy, _stream(x))
+    check(rc, "pwc_lattice_unsplit_f32")
     return out
 
 

@@ -1031,3 +1031,69 @@ def test_forward_winograd4_error_budget(gpu_device, monkeypatch):
         e4, e2 = O.epe(res["1"][0][i:i + 1], ref), O.epe(res["0"][0][i:i + 1], ref)
         print("item %d vs CPU oracle: F(4x4) route EPE %.3e, F(2x2) route %.3e" % (i, e4, e2))
         assert e4 < 1e-4 and e2 < 1e-4
+
+
+@pytest.mark.gpu
+def test_split2_store_and_lattice_unsplit(gpu_device):
+    """PWC_CONV_SPLIT2 + pwc_lattice_unsplit_f32 (round 3): a layer stores its result as its four pixel lattices so that the next,
+    twice-as-dilated layer of the context network (PWCNet.py:126-131) is a dilation-1 convolution on 4x as many half-size images.
+    (1) the split store holds exactly the plain result re-ordered; (2) nested three times and unsplit it is the identity; (3) a
+    dilation-2 convolution on the normal layout == a dilation-1 convolution on the split layout (against torch fp64)."""
+    from opticalflow_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, cin, cout, H, W = 2, 40, 64, 16, 64
+    x = torch.randn(B, cin, H, W, generator=g).to(gpu_device)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).to(gpu_device)
+    b = (torch.randn(cout, generator=g) * 0.1).to(gpu_device)
+    up = ops.pack_conv3x3_wino4(w)
+    plain = ops.conv3x3_wino4(x, up, b, cout)
+    split = ops.conv3x3_wino4(x, up, b, cout, split2=True)
+    assert split.shape == (4 * B, cout, H // 2, W // 2)
+    for bb in range(B):
+        for py in range(2):
+            for px in range(2):
+                assert torch.equal(split[4 * bb + 2 * py + px], plain[bb, :, py::2, px::2])
+    assert torch.equal(ops.lattice_unsplit(split, B, 1), plain)
+    # three nested splits by hand (the order the context network produces) and the unsplit kernel
+    t = torch.randn(1, 3, 16, 32, generator=g).to(gpu_device)
+    lat = t
+    for _ in range(3):
+        n, c, h, ww = lat.shape
+        lat = torch.stack([lat[:, :, py::2, px::2] for py in range(2) for px in range(2)], 1).reshape(n * 4, c, h // 2, ww // 2).contiguous()
+    assert torch.equal(ops.lattice_unsplit(lat, 1, 3), t)
+    # dilation 2 on the normal layout == dilation 1 on the lattices
+    w2 = (torch.randn(32, cout, 3, 3, generator=g) * (2.0 / (cout * 9)) ** 0.5).to(gpu_device)
+    b2 = torch.zeros(32, device=gpu_device)
+    ref = F.leaky_relu(F.conv2d(plain.cpu().double(), w2.cpu().double(), b2.cpu().double(), padding=2, dilation=2), 0.1)
+    on_lat = ops.conv3x3_wino4(split, ops.pack_conv3x3_wino4(w2), b2, 32)
+    back = ops.lattice_unsplit(on_lat, B, 1).cpu().double()
+    assert (back - ref).abs().max().item() <= 1e-6 * (cout * 9) ** 0.5 * max(1.0, plain.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.conv3x3_wino4(x[:, :, :15], up, b, cout, split2=True)
+
+
+@pytest.mark.gpu
+def test_forward_context_lattice_layout_matches_plain_layout(gpu_device, monkeypatch):
+    """The context network in lattice-major layout (engine.PwcPlan._context_lattice) against the same forward with PWC_CTX_LATTICE=0
+    at the benchmark geometry: every layer computes the reference's layer on the same values, only the storage order between them
+    differs -- the flows agree to fp32 rounding (different kernels / tile shapes), and item 3 is checked against the CPU oracle."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    xc = torch.rand(16, 6, 448, 1024, generator=torch.Generator().manual_seed(4321))
+    x = xc.to(gpu_device)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PWC_CTX_LATTICE", flag)
+        net = PWCDCNet()
+        sd = synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02)
+        net.load_state_dict(sd)
+        net = net.to(gpu_device).eval()
+        out[flag] = net(x).clone()
+        assert net._plan_for(x).ctx_lattice == (flag == "1")
+    d = O.epe(out["1"].cpu(), out["0"].cpu())
+    print("context network lattice-major vs plain layout: EPE %.3e" % d)
+    assert d < 2e-5
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.pwc_forward(sd, xc[3:4])
+    assert O.epe(out["1"][3:4].cpu(), ref) < 1e-4
