@@ -834,9 +834,10 @@ def test_conv3x3_winograd_split_k(gpu_device):
     """A launch of 32..159 workgroups is cut along Cin (levels 5-4 at batch 16); partial sums through the caller's workspace and
     a fixed-order reduction.  Same bound as the unsplit kernel; without a workspace the layer runs unsplit."""
     from opticalflow_amd import ops
-    B, cin, cout, H, W = 4, 80, 128, 32, 128
+    B, cin, cout, H, W = 4, 264, 128, 32, 128
     need = ops.conv3x3_wino_workspace_bytes(B, cin, H, W, cout)
-    assert need == 2 * B * cout * H * W * 4                      # 128 workgroups, 20 chunks -> 2 slices of 10
+    assert need == 3 * B * cout * H * W * 4                      # 128 workgroups, 66 chunks -> 3 slices of 22
+    assert ops.conv3x3_wino_workspace_bytes(B, 80, H, W, cout) == 0      # a short K (20 chunks) is not worth splitting (round 3)
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5

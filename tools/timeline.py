@@ -38,7 +38,7 @@ def short(n):
     for k in ("pyr1_fused", "corr81_bwd", "corr81_c8", "warp_c8", "nchw_to_c8_hilo", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
         if k in n:
             return k
-    for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "splitk_reduce", "warp_kernel", "copyBuffer", "elementwise", "pack3x3"):
+    for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "splitk_reduce", "warp_kernel", "copyBuffer", "elementwise", "pack3x3", "lattice_unsplit"):
         if k in n:
             return k
     return n[:30]
