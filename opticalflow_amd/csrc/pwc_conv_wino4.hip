@@ -9,20 +9,21 @@
 // The route is therefore GATED: pwc_conv3x3_wino4_preferred() only says yes for the large level-2 / level-3 layers, the per-layer
 // error stays inside the tests' 3e-6*sqrt(9 Cin) bound with margin, and the whole-forward EPE against the oracle is asserted at 1e-4.
 //
-// Design -- everything a (cout, tile) pair needs lives in ONE lane, so there is no cross-wave exchange at all:
+// Design -- the B operand never passes through LDS: a lane makes it from its own patch.
 //   v_mfma_f32_16x16x4_f32: A = U_p[16 couts][4 cin], B = V_p[4 cin][16 tiles], D = 16 couts x 16 tiles = 4 accumulator registers
-//   per lane and position; a wave owns one (16-cout block, 16-tile group) and ALL 36 positions = 144 accumulator registers.
+//   per lane and position; a wave owns two 16-cout blocks x one 16-tile group x 18 of the 36 positions = 144 accumulator registers.
 //   Lane (n = lane % 16, k = lane / 16): channel k of the 4-channel chunk, tile n of the group.
-//     B operand: the lane reads ITS 6x6 patch of channel k (6 x (ds_read_b128 + ds_read_b64)) and makes the 36 values of
-//                Bt d B itself -- 12 fused multiply-adds per 1-D transform, rows first (one patch row per phase, one chunk
-//                ahead), then one column per phase right before the six MFMAs that consume it;
+//     B operand: the lane reads ITS 6x6 patch of channel k (6 x 2 ds_read_b128) and makes the 18 values of Bt d B its wave needs
+//                itself -- rows first (two patch rows per phase, one chunk ahead), then one column per phase right before the
+//                twelve MFMAs that consume it (each value feeds both cout blocks);
 //     A operand: U in LDS as [position / 4][cin][cout][position % 4]: four positions per ds_read_b128, conflict-free;
-//     epilogue : At M A for the lane's 4 couts x 1 tile in registers, bias, LeakyReLU, four 16-byte stores per cout.
-//   Workgroup = 8 waves = CB cout blocks x TG tile groups (<4,2>: 64 couts x 8 rows x 64 columns; <2,4>: 32 couts x 16 x 64);
-//   a tile group is one row of sixteen 4x4 tiles.  Cin runs in chunks of 4 channels through LDS rings of three slots filled by
+//     epilogue : At M A for the lane's couts x 1 tile in registers (the two waves of a pair exchange half of their partial sums
+//                through LDS once), bias, LeakyReLU, four 16-byte stores per cout.
+//   Workgroup = 8 waves = 4 pairs = CB/2 32-cout groups x TG tile groups (<4,2>: 64 couts x 8 rows x 64 columns; <2,4>: 32 couts x
+//   16 x 64); a tile group is one row of sixteen 4x4 tiles.  Cin runs in chunks of 4 channels through LDS rings of three slots filled by
 //   LDS-DMA in 16-byte pieces: raw input tile [4][4 TG + 2 rows][72] (global columns ox0 - 4 .. ox0 + 67; the range check
 //   supplies padding, edges and the ragged last chunk), U [9][4][16 CB][4].  Dilation 1 only.  One barrier per chunk:
-//     iteration k:  wait {raw(k+1), U(k)} | 36 MFMAs on U(k), V(k) | issue raw(k+3), U(k+2) | rows of raw(k+1) -> w(k+1)
+//     iteration k:  wait {raw(k+1), U(k)} | 36 MFMAs per wave on U(k), V(k) | issue raw(k+3), U(k+2) | rows of raw(k+1) -> w(k+1)
 #include <stdlib.h>
 
 #include <type_traits>
@@ -94,31 +95,6 @@ __device__ __forceinline__ void bt6(const float (&d)[6], float (&t)[6]) {
     t[5] = __builtin_fmaf(kA2B2, d[1], __builtin_fmaf(-kS2, d[3], d[5]));
 }
 
-// The same transform in three parts of four operations (one part per MFMA shadow: an MFMA of 32 cycles hides ~24 cycles of other
-// vector issue, i.e. at most six VALU operations; twelve in one gap cost 24 cycles each time), each pinned where it is written.
-template <int PART>
-__device__ __forceinline__ void bt6_part(const float (&d)[6], float (&t)[6]) {
-#if defined(PWC_W4_EXP) && (PWC_W4_EXP & 8)
-    t[2 * PART] = d[2 * PART]; t[(2 * PART + 5) % 6] = d[PART];
-    return;
-#endif
-    if constexpr (PART == 0) {
-        t[0] = __builtin_fmaf(kA2B2, d[0], __builtin_fmaf(-kS2, d[2], d[4]));
-        t[5] = __builtin_fmaf(kA2B2, d[1], __builtin_fmaf(-kS2, d[3], d[5]));
-        asm volatile("" : "+v"(t[0]), "+v"(t[5]));
-    } else if constexpr (PART == 1) {
-        const float p = __builtin_fmaf(-kB2, d[2], d[4]), q = __builtin_fmaf(-kB2, d[1], d[3]);
-        t[1] = __builtin_fmaf(kA, q, p);
-        t[2] = __builtin_fmaf(-kA, q, p);
-        asm volatile("" : "+v"(t[1]), "+v"(t[2]));
-    } else {
-        const float r = __builtin_fmaf(-kA2, d[2], d[4]), s = __builtin_fmaf(-kA2, d[1], d[3]);
-        t[3] = __builtin_fmaf(kB, s, r);
-        t[4] = __builtin_fmaf(-kB, s, r);
-        asm volatile("" : "+v"(t[3]), "+v"(t[4]));
-    }
-}
-
 // The optimiser sinks pure arithmetic towards its first use: without this pin the six row transforms of an iteration (whose results
 // are consumed one iteration later) all ended up in ONE MFMA shadow of the next iteration -- 72 VALU operations in a row and 36
 // patch values kept alive across the barrier (spills).  An empty volatile asm that "modifies" the values keeps them where they are.
@@ -170,11 +146,39 @@ wino4_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, 
 
 #define PWC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 
-template <int CB, int TG>
-__global__ void __launch_bounds__(kThreads, 1)
-conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
-                     float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                     int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
+// ---- the kernel: pair-split positions ------------------------------------------------------------------------------------------------
+// The first version gave every wave 16 couts x 16 tiles x all 36 positions (no exchange at all), so the FOUR waves that share a tile
+// group each made the same 36 B operands: 144 VALU operations per 36 MFMAs of 32 cycles, the largest single cost (20 % of its time;
+// ablations in profiles/r03_wino4_notes.md; dc_conv1 1.78 ms).  Here a wave owns 32 couts (two 16-cout blocks) x 16 tiles x 18
+// positions -- the three columns j = 3 hj .. 3 hj + 2 of the 6x6 position grid, all rows -- so one B operand feeds TWO MFMAs and the wave
+// only transforms what its three columns need: 6 operations per patch row instead of 12, three column transforms instead of six =
+// 72 VALU per 36 MFMAs, and the row-transformed patch is 18 registers instead of 36 (dc_conv1 1.61 ms).  The two waves of a pair
+// (hj = 0, 1) hold complementary halves of sum_j T[.][j] At[.][j]: at the end each sends the partial 4x4 outputs of the cout block it
+// does NOT finish through LDS (64 floats per lane) and finishes the other.
+template <int HJ>
+__device__ __forceinline__ void bt3_row(const float (&d)[6], float (&t)[3]) {      // outputs 3 HJ .. 3 HJ + 2 of bt6: 6 operations
+#if defined(PWC_W4_EXP) && (PWC_W4_EXP & 8)
+    t[0] = d[0]; t[1] = d[1]; t[2] = d[2];
+    return;
+#endif
+    if constexpr (HJ == 0) {
+        t[0] = __builtin_fmaf(kA2B2, d[0], __builtin_fmaf(-kS2, d[2], d[4]));
+        const float p = __builtin_fmaf(-kB2, d[2], d[4]), q = __builtin_fmaf(-kB2, d[1], d[3]);
+        t[1] = __builtin_fmaf(kA, q, p);
+        t[2] = __builtin_fmaf(-kA, q, p);
+    } else {
+        const float r = __builtin_fmaf(-kA2, d[2], d[4]), s = __builtin_fmaf(-kA2, d[1], d[3]);
+        t[0] = __builtin_fmaf(kB, s, r);
+        t[1] = __builtin_fmaf(-kB, s, r);
+        t[2] = __builtin_fmaf(kA2B2, d[1], __builtin_fmaf(-kS2, d[3], d[5]));
+    }
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]));
+}
+
+template <int CB, int TG, int HJ>
+__device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+                                            float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                                            int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
     using G = Geo4<CB, TG>;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 3 x [raw | U]
 
@@ -183,7 +187,8 @@ conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     const int lane = tid & 63;
     const int n = lane & 15;                  // tile of the group (B / D column)
     const int kq = lane >> 4;                 // channel of the chunk (A / B k index); D rows 4 kq .. 4 kq + 3
-    const int cbi = wave % CB, tgi = wave / CB;
+    const int pr = wave >> 1;                           // pair = (32-cout group, tile group); the position half hj = wave & 1 is the template parameter HJ
+    const int cg2 = pr % (CB / 2), tgi = pr / (CB / 2);
 
     // One-dimensional grid of nblk tiles x ngroups cout groups.  Workgroups i, i+8, ... share an XCD: each XCD gets a contiguous run of
     // tiles (halo re-reads hit its L2) and runs the cout groups of one tile BACK TO BACK, so that the second group finds the input
@@ -235,10 +240,6 @@ conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, 
     const int ubytes = (int)(uchunk - (int64_t)cb0 * 4) * 4;
     const unsigned lds0 = pwc::lds_addr(smem);
 
-#if 0
-#define PWC_W4_EXP_UNUSED 0          // timing experiments (results invalid): 1 = every U fetch reads chunk 0, 2 = every raw fetch reads chunk 0,
-                              // 4 = no LDS-DMA inside the loop, 8 = no input transforms (bt6), 16 = no barrier / counted wait, 32 = no patch-row reads
-#endif
     auto issue_raw = [&](int chunk) {                                 // raw(chunk) -> slot chunk % 3, one float to the right
         // a chunk past the end gets a zero-sized descriptor: every lane fails the range check, nothing is fetched, zeros land in a slot
         // nobody reads -- so EVERY iteration issues a whole group and the counted waits never change
@@ -266,174 +267,183 @@ conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, 
         if (n_grp == kN0) PWC_WAIT_VMCNT(2 * kN0); else if (n_grp == kN0 - 1) PWC_WAIT_VMCNT(2 * kN0 - 2); else PWC_WAIT_VMCNT(2 * kN0 - 4);
     };
 
-    // this lane's patch inside a raw slot: channel kq, rows 4 tgi .. 4 tgi + 5, columns 4 n .. 4 n + 5
+
+    // this lane's patch inside a raw slot: channel kq, rows 4 tgi .. 4 tgi + 5, columns 4 n .. 4 n + 5 (+ 4: see kRawW)
     const int poff = kq * G::kPlane + (4 * tgi) * kRawW + 4 + 4 * n;
-    // this lane's U column inside a slot's U image: [g][k = kq][cout = 16 cbi + n][4]
-    const int uoff = G::kRawFloats + (kq * G::kCoutT + 16 * cbi + n) * 4;
+    // this lane's U column inside a slot's U image: [g][k = kq][cout = 32 cg2 + 16 cbl + n][4]
+    const int uoff = G::kRawFloats + (kq * G::kCoutT + 32 * cg2 + n) * 4;
     constexpr int kUG = kCK * G::kCoutT * 4;              // floats per position group g
-
-    f32x4 acc[36];
-
-    // LDS reads through ONE opaque per-iteration base register + immediate offsets.  (Left to itself the compiler folds the ring slot
-    // into per-read constants beyond the 16-bit offset field and keeps a separate address register for every U group and patch row:
-    // ~10 registers and as many VALU operations per iteration.)
     typedef const __attribute__((address_space(3))) f32x4 *lds4_t;
     auto lds_read4 = [](unsigned base_bytes, int off_bytes) { return *reinterpret_cast<lds4_t>((uintptr_t)(base_bytes + off_bytes)); };
-    auto load_row = [&](unsigned base_bytes, int a, float (&d)[6]) {   // patch row a of this lane's channel / tile
+    auto load_row = [&](unsigned base_bytes, int a, float (&d)[6]) {
         const f32x4 v = lds_read4(base_bytes, a * kRawW * 4);
-        const f32x4 u = lds_read4(base_bytes, a * kRawW * 4 + 16);          // 16-byte reads are conflict-free here, 8-byte ones 2-way
+        const f32x4 u = lds_read4(base_bytes, a * kRawW * 4 + 16);
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; d[4] = u[0]; d[5] = u[1];
     };
     const unsigned poff_b = lds0 + (unsigned)poff * 4u, uoff_b = lds0 + (unsigned)uoff * 4u;
 
-    float wA[6][6], wB[6][6];                 // row-transformed patches: w[a][j] = sum_b d[a][b] Bt[j][b]; ping-pong over chunks
-    float vE[6], vO[6];                       // V columns (six positions each): even / odd columns of the position grid
-    f32x4 ua7 = {0.f, 0.f, 0.f, 0.f}, ua8 = {0.f, 0.f, 0.f, 0.f};      // U groups 7, 8 (positions 28..35) carried into the next iteration
+    f32x4 acc[2][18];                         // [cout block][local position 6 jj + i]
+    float wA[6][3], wB[6][3];                 // row-transformed patch, this wave's three columns; ping-pong over chunks
+    float v0[6], v1[6];                       // V columns, alternating over the SEQUENCE of columns (three per chunk: the parity flips per chunk)
+    f32x4 uc[2][2];                           // U groups of column jj = 2 (both cout blocks), carried into the next iteration's first phase
 #pragma unroll
-    for (int i = 0; i < 6; ++i) vO[i] = 0.f;  // "column 5 of chunk -1" adds 0 * 0
+    for (int i = 0; i < 6; ++i) v0[i] = v1[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) uc[c][0] = uc[c][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // One iteration = six phases of six MFMAs.  The iteration is ROTATED by one phase: it starts with column 5 of chunk k - 1, whose
-    // operands (U groups 7, 8 and the V column) were put into registers before the barrier, so the matrix pipe restarts right behind
-    // the barrier while the first U reads of chunk k are in flight; then columns 0..4 of chunk k.  Phase ph = 0..5 (0 = the rotated
-    // one) also makes V column ph of THIS chunk from w(k) (three parts in the shadows of its MFMAs 0..2) and the row transform of
-    // patch row ph of the NEXT chunk (three parts behind MFMAs 3..5; the row was read one phase earlier): exactly four VALU
-    // operations per MFMA.  U groups are read one phase ahead.
-    // Transform schedule, measured (tools/wino4_exp.sh, dc_conv1 / conv2_4): 2 = all 24 operations of a phase behind ONE MFMA 1806 / 491 us,
-    // 1 = two blocks of twelve 1823 / 497, 0 = four per MFMA 1921 / 519.  Evenly spread VALU work is the SLOWEST: with two waves per SIMD
-    // a wave in a long VALU burst leaves the matrix pipe to its partner, a wave that sprinkles VALU into every gap competes in every gap.
-#ifndef PWC_W4_BLOCK
-#define PWC_W4_BLOCK 2
-#endif
-    constexpr int kBlockSched = PWC_W4_BLOCK;
-    auto iteration = [&](int k, float (&wc)[6][6], float (&wn)[6][6]) {
-        // group G(k) = {raw(k+1), U(k)} has landed; G(k+1) = {raw(k+2), U(k+1)} may stay in flight.  (Past the last chunk the groups
-        // are zero-sized fetches and the patch rows read are zeros or stale data whose transforms nobody uses: no special cases.)
+    // U groups of local column jj: global positions 6 (3 HJ + jj) .. + 5 lie in exactly two groups of four
+    auto g0_of = [](int jj) { return (6 * (3 * HJ + jj)) >> 2; };
+#define PWC_W4P_MFMA(CBL, Q, UG, VB) acc[CBL][Q] = __builtin_amdgcn_mfma_f32_16x16x4f32((UG), (VB), acc[CBL][Q], 0, 0, 0)
+
+    // One iteration = three phases of twelve MFMAs (6 rows x 2 cout blocks), rotated by one phase: column 2 of chunk k - 1 first (its
+    // operands are in registers behind the barrier), then columns 0, 1 of chunk k.  Phase ph also makes V column ph of this chunk and
+    // the row transforms of patch rows 2 ph, 2 ph + 1 of the next chunk (24 VALU behind one MFMA), and reads the U groups of column ph.
+    // PAR = parity of the chunk: column s of the running sequence of columns uses V buffer s & 1.
+    auto iteration = [&](int k, float (&wc)[6][3], float (&wn)[6][3], auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
         if (!(PWC_W4_EXP & 16)) {
             wait_groups1();
             __syncthreads();
         }
         unsigned uslot = uoff_b + (unsigned)__builtin_amdgcn_readfirstlane((k % 3) * G::kSlot * 4);
         unsigned rnext = poff_b + (unsigned)__builtin_amdgcn_readfirstlane(((k + 1) % 3) * G::kSlot * 4);
-        asm volatile("" : "+v"(uslot), "+v"(rnext));            // opaque bases (see lds_read4)
-        f32x4 ua0, ua1, ua2, ua3, ua4, ua5, ua6;
-        float d0[6], d1[6];
-        auto ldu = [&](int g) { return lds_read4(uslot, g * kUG * 4); };
-#define PWC_W4_MFMA(P, UA, VB) acc[P] = __builtin_amdgcn_mfma_f32_16x16x4f32((UA)[(P) & 3], (VB), acc[P], 0, 0, 0)
+        asm volatile("" : "+v"(uslot), "+v"(rnext));
+        f32x4 un[2][2];                                         // U groups of the column the NEXT phase multiplies
+        float da[6], db[6];
 #pragma unroll
-        for (int ph = 0; ph < 6; ++ph) {
-            const int j = ph - 1;                               // column of chunk k this phase multiplies (ph 0: column 5 of chunk k - 1)
+        for (int ph = 0; ph < 3; ++ph) {
+            // this phase multiplies: ph 0 -> column 2 of chunk k - 1 (U in uc), ph 1 -> column 0, ph 2 -> column 1 (U in un of the previous phase)
+            const int jj = (ph + 2) % 3;
+            // V buffer parities along the running sequence of columns (chunk k's columns are elements 3k, 3k+1, 3k+2; 3k = k mod 2)
+            const bool use_v1 = ph == 0 ? ((PAR + 1 + 2) & 1) : ((PAR + ph - 1) & 1);
+            f32x4 (&ucur)[2][2] = uc;                           // loaded during the previous phase
+            const int p0 = 6 * (3 * HJ + jj), gb = p0 >> 2;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                if (ph == 0) {
-                    if (i < 2) PWC_W4_MFMA(30 + i, ua7, vO[i]); else PWC_W4_MFMA(30 + i, ua8, vO[i]);
-                } else {
-                    const int p = 6 * j + i, g = p >> 2;
-                    const f32x4 &ug_ = g == 0 ? ua0 : g == 1 ? ua1 : g == 2 ? ua2 : g == 3 ? ua3 : g == 4 ? ua4 : g == 5 ? ua5 : g == 6 ? ua6 : ua7;
-                    if (j & 1) PWC_W4_MFMA(p, ug_, vO[i]); else PWC_W4_MFMA(p, ug_, vE[i]);
-                }
+            for (int m = 0; m < 12; ++m) {
+                const int cbl = m / 6, i = m % 6;               // cout block major: its two U groups die after six MFMAs
+                const int p = p0 + i;
+                if (use_v1) PWC_W4P_MFMA(cbl, 6 * jj + i, ucur[cbl][(p >> 2) - gb][p & 3], v1[i]);
+                else        PWC_W4P_MFMA(cbl, 6 * jj + i, ucur[cbl][(p >> 2) - gb][p & 3], v0[i]);
                 // ---- in the shadow of this MFMA ----------------------------------------------------------------------
-                if (i == 0) {                                   // U groups of the next phase's column; patch row(s) of the next chunk
-                    if (ph == 0) { ua0 = ldu(0); ua1 = ldu(1); }
-                    if (ph == 1) ua2 = ldu(2);
-                    if (ph == 2) { ua3 = ldu(3); ua4 = ldu(4); }
-                    if (ph == 3) ua5 = ldu(5);
-                    if (ph == 4) { ua6 = ldu(6); ua7 = ldu(7); }
-                    if (ph == 5) ua8 = ldu(8);
-                    if (!(PWC_W4_EXP & 32)) {
-                        if (ph == 0) { load_row(rnext, 0, d0); load_row(rnext, 1, d1); }
-                        else if (ph < 5) load_row(rnext, ph + 1, ((ph + 1) & 1) ? d1 : d0);
-                    }
-                }
-                if (ph == 0 && i == 1 && !(PWC_W4_EXP & 4)) issue_raw(k + 3);
-                if (ph == 0 && i == 2 && !(PWC_W4_EXP & 4)) issue_u(k + 2);
-                {
+                if (m == 0 && !(PWC_W4_EXP & 32)) { load_row(rnext, 2 * ph, da); load_row(rnext, 2 * ph + 1, db); }
+                if (ph == 0 && m == 1 && !(PWC_W4_EXP & 4)) issue_raw(k + 3);
+                if (ph == 0 && m == 2 && !(PWC_W4_EXP & 4)) issue_u(k + 2);
+                if (m == 4) {                                   // V column ph of THIS chunk (consumed by the next phase) + two row transforms
                     const float col[6] = {wc[0][ph], wc[1][ph], wc[2][ph], wc[3][ph], wc[4][ph], wc[5][ph]};
-                    float (&vdst)[6] = (ph & 1) ? vO : vE;
-                    float (&dsrc)[6] = (ph & 1) ? d1 : d0;
-                    if (kBlockSched == 2) {                     // all twenty-four operations of the phase behind MFMA 2
-                        if (i == 2) {
-                            bt6_part<0>(col, vdst); bt6_part<1>(col, vdst); bt6_part<2>(col, vdst);
-                            bt6_part<0>(dsrc, wn[ph]); bt6_part<1>(dsrc, wn[ph]); bt6_part<2>(dsrc, wn[ph]);
-                        }
-                    } else if (kBlockSched) {                   // twelve operations behind MFMA 2 (column) and MFMA 4 (row)
-                        if (i == 2) { bt6_part<0>(col, vdst); bt6_part<1>(col, vdst); bt6_part<2>(col, vdst); }
-                        if (i == 4) { bt6_part<0>(dsrc, wn[ph]); bt6_part<1>(dsrc, wn[ph]); bt6_part<2>(dsrc, wn[ph]); }
-                    } else if (i < 3) {                         // V column ph of this chunk, part i
-                        if (i == 0) bt6_part<0>(col, vdst); else if (i == 1) bt6_part<1>(col, vdst); else bt6_part<2>(col, vdst);
-                    } else {                                    // row transform of patch row ph of the next chunk, part i - 3
-                        if (i == 3) bt6_part<0>(dsrc, wn[ph]); else if (i == 4) bt6_part<1>(dsrc, wn[ph]); else bt6_part<2>(dsrc, wn[ph]);
-                    }
+                    const bool dst_v1 = (PAR + ph) & 1;
+                    if (dst_v1) { bt6(col, v1); pin6(v1); } else { bt6(col, v0); pin6(v0); }
+                }
+                if (m == 8) { bt3_row<HJ>(da, wn[2 * ph]); bt3_row<HJ>(db, wn[2 * ph + 1]); }
+                // U groups of column ph of this chunk, multiplied by the next phase (phase 2's: by the next iteration's phase 0)
+                if (m == 6 || m == 10) {
+                    const int cb_ = m == 6 ? 0 : 1;
+                    const int gn = g0_of(ph);
+                    un[cb_][0] = lds_read4(uslot, gn * kUG * 4 + cb_ * 16 * 16);
+                    un[cb_][1] = lds_read4(uslot, (gn + 1) * kUG * 4 + cb_ * 16 * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { uc[c][0] = un[c][0]; uc[c][1] = un[c][1]; }
         }
     };
 
-    // ---- prologue: raw(0) alone (its row transform precedes the loop), then the groups G(0) = {raw(1), U(0)}, G(1) = {raw(2), U(1)}
+    // ---- prologue: raw(0) alone, then the groups G(0) = {raw(1), U(0)}, G(1) = {raw(2), U(1)}
     issue_raw(0);
     issue_raw(1);
     issue_u(0);
     issue_raw(2);
     issue_u(1);
-    wait_groups2();                                    // raw(0) has landed
+    wait_groups2();
     __syncthreads();
     {
         float d[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
             load_row(poff_b, a, d);
-            bt6(d, wA[a]);
+            bt3_row<HJ>(d, wA[a]);
         }
     }
 #pragma unroll
-    for (int p = 0; p < 36; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};       // (zeroed here: 144 registers less across the prologue)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the later-dispatched wave of each SIMD loses every issue arbitration otherwise
-
-    for (int k = 0; k < nchunks; k += 2) {             // two copies of the body: the w arrays ping-pong without register moves
-        iteration(k, wA, wB);
-        if (k + 1 < nchunks) iteration(k + 1, wB, wA);
-    }
-    // column 5 of the last chunk
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        if (i < 2) PWC_W4_MFMA(30 + i, ua7, vO[i]); else PWC_W4_MFMA(30 + i, ua8, vO[i]);
-    }
-#undef PWC_W4_MFMA
+        for (int q = 0; q < 18; ++q) acc[c][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-    // ---- output transform At M A for this lane's 4 couts x 1 tile, bias, LeakyReLU, 16-byte stores ----------------
-    // (lane coordinates re-derived from the hardware lane id: keeping them alive across the loop cost two spilled registers, and a
-    // kernel that touches scratch at all pays for the scratch set-up of every workgroup)
+    for (int k = 0; k < nchunks; k += 2) {
+        iteration(k, wA, wB, std::integral_constant<int, 0>{});
+        if (k + 1 < nchunks) iteration(k + 1, wB, wA, std::integral_constant<int, 1>{});
+    }
+    // column 2 of the last chunk: its V is in the buffer of sequence element 3 (nchunks - 1) + 2, its U groups in uc
+    {
+        const int p0 = 6 * (3 * HJ + 2), gb = p0 >> 2;
+        const bool use_v1 = (nchunks - 1) & 1;                  // sequence element 3 (nchunks - 1) + 2
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            const int cbl = m / 6, i = m % 6, p = p0 + i;
+            if (use_v1) PWC_W4P_MFMA(cbl, 12 + i, uc[cbl][(p >> 2) - gb][p & 3], v1[i]);
+            else        PWC_W4P_MFMA(cbl, 12 + i, uc[cbl][(p >> 2) - gb][p & 3], v0[i]);
+        }
+    }
+#undef PWC_W4P_MFMA
+
+    // ---- output transform: partial sums over this wave's three columns for both cout blocks; the block 1 - HJ half goes to the partner
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    __syncthreads();                                            // every wave is done with the rings
+    float *xsend = smem + (wave * 64) * 64 + lane_e;            // [wave][64 values][64 lanes]
+    const float *xrecv = smem + ((wave ^ 1) * 64) * 64 + lane_e;
+    float keep[4][4][4];                                        // [cout c][row pp][col q] partial outputs of the block this wave finishes
+#pragma unroll
+    for (int cbl = 0; cbl < 2; ++cbl) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float t[4][3];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const float m[6] = {acc[cbl][6 * jj + 0][c], acc[cbl][6 * jj + 1][c], acc[cbl][6 * jj + 2][c],
+                                    acc[cbl][6 * jj + 3][c], acc[cbl][6 * jj + 4][c], acc[cbl][6 * jj + 5][c]};
+                float o[4];
+                at6(m, o);
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) t[pp][jj] = o[pp];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                float o[4];
+                if constexpr (HJ == 0) {                        // columns 0, 1, 2 = points 0, +a, -a
+                    const float s = t[pp][1] + t[pp][2], d = t[pp][1] - t[pp][2];
+                    o[0] = t[pp][0] + s; o[1] = kA * d; o[2] = kA2 * s; o[3] = kA3 * d;
+                } else {                                        // columns 3, 4, 5 = points +b, -b, infinity
+                    const float s = t[pp][0] + t[pp][1], d = t[pp][0] - t[pp][1];
+                    o[0] = s; o[1] = kB * d; o[2] = kB2 * s; o[3] = __builtin_fmaf(kB3, d, t[pp][2]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (cbl == HJ) keep[c][pp][q] = o[q];
+                    else xsend[((c * 4 + pp) * 4 + q) * 64] = o[q];
+                }
+            }
+        }
+    }
+    __syncthreads();
     const int oyl = oy0 + 4 * tgi, ox = ox0 + 4 * (lane_e & 15);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int co = cb0 + 16 * cbi + 4 * (lane_e >> 4) + c;
-        float t[4][6];                                          // At applied along i (rows) for every column j
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const float m[6] = {acc[6 * j + 0][c], acc[6 * j + 1][c], acc[6 * j + 2][c], acc[6 * j + 3][c], acc[6 * j + 4][c], acc[6 * j + 5][c]};
-            float o[4];
-            at6(m, o);
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) t[pp][j] = o[pp];
-        }
+        const int co = cb0 + 32 * cg2 + 16 * HJ + 4 * (lane_e >> 4) + c;
         const float bv = bias[min(co, Cout - 1)];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             float o[4];
-            at6(t[pp], o);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                o[q] += bv;
+                o[q] = keep[c][pp][q] + xrecv[((c * 4 + pp) * 4 + q) * 64] + bv;
                 if (do_leaky) o[q] = leaky(o[q], slope);
             }
             const int oy = oyl + pp;
-            if (co < Cout && oy < H && ox < W) {                 // W % 4 == 0: the four pixels are inside together
+            if (co < Cout && oy < H && ox < W) {
                 if (!split2) {
                     *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + (int64_t)co * plane + (int64_t)oy * W + ox) = (f32x4){o[0], o[1], o[2], o[3]};
                 } else {
-                    // PWC_CONV_SPLIT2: image b is written as FOUR images 4b + 2 (oy & 1) + (ox & 1) of (H/2) x (W/2) -- the pixel
-                    // lattices of the next, twice-as-dilated layer, which then runs as a dilation-1 convolution on 4B small images
                     float *d0 = y + ((int64_t)b * 4 + 2 * (oy & 1)) * bsy + (int64_t)co * (plane >> 2) + (int64_t)(oy >> 1) * (W >> 1) + (ox >> 1);
                     *reinterpret_cast<f32x2 *>(d0) = (f32x2){o[0], o[2]};
                     *reinterpret_cast<f32x2 *>(d0 + bsy) = (f32x2){o[1], o[3]};
@@ -441,6 +451,18 @@ conv3x3_wino4_kernel(const float *__restrict__ x, const float *__restrict__ up, 
             }
         }
     }
+}
+
+template <int CB, int TG>
+__global__ void __launch_bounds__(kThreads, 1)
+conv3x3_wino4p_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
+                      float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                      int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
+    // the position half is wave-uniform: two specialisations of the body, every index inside is a compile-time constant
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 1)
+        wino4p_body<CB, TG, 1>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
+    else
+        wino4p_body<CB, TG, 0>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
 }
 
 // Inverse of L nested PWC_CONV_SPLIT2 stores (see pwc_hip.h): one thread per four output pixels of a row; the four come from four
@@ -473,18 +495,19 @@ template <int CB, int TG>
 int launch_wino4(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout,
                  int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups, int split2) {
     using G = Geo4<CB, TG>;
+    constexpr int kSmemAttr = G::kSmemBytes > 8 * 64 * 64 * 4 ? G::kSmemBytes : 8 * 64 * 64 * 4;
     static pwc::LdsAttrOnce once;
-    if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino4_kernel<CB, TG>), G::kSmemBytes,
-                                            "conv3x3_wino4_kernel"))
+    if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino4p_kernel<CB, TG>), kSmemAttr, "conv3x3_wino4p_kernel"))
         return rc;
     const int CoutP = cout_padded4(Cout);
     const int tiles_x = (W + kGW - 1) / kGW, tiles_y = (H + 4 * TG - 1) / (4 * TG);
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
     if (nblk * ngroups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
-    hipLaunchKernelGGL((conv3x3_wino4_kernel<CB, TG>), dim3((unsigned)(nblk * ngroups)), dim3(kThreads), G::kSmemBytes, st,
+    constexpr int kSmemP = G::kSmemBytes > 8 * 64 * 64 * 4 ? G::kSmemBytes : 8 * 64 * 64 * 4;       // rings, or the 128 KiB of the final exchange
+    hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG>), dim3((unsigned)(nblk * ngroups)), dim3(kThreads), kSmemP, st,
                        x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, (int)nblk, ngroups, split2);
-    pwc::note_kernel("conv3x3_wino4_kernel", CB, TG, 1, 1, 1, 0);
-    return pwc::check_launch("conv3x3_wino4_kernel");
+    pwc::note_kernel("conv3x3_wino4p_kernel", CB, TG, 1, 1, 1, 0);
+    return pwc::check_launch("conv3x3_wino4p_kernel");
 }
 
 }  // namespace

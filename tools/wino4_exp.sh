@@ -5,7 +5,7 @@
 # -DPWC_W4_BLOCK=0|1: transform schedule (spread: four operations per MFMA / blocks of twelve).  Restores the normal build at the end.
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$ROOT/opticalflow_amd/csrc"
-for e in ${PWC_EXPS:--DPWC_W4_EXP=0 -DPWC_W4_EXP=3}; do
+for e in ${PWC_EXPS:--DPWC_W4_EXP=0 -DPWC_W4_EXP=3 -DPWC_W4_EXP=7 -DPWC_W4_EXP=19}; do
   rm -f build/pwc_conv_wino4.o; make EXTRA="$e" > /dev/null 2>&1
   echo "== $e"; python3 "$ROOT/tools/bench_wino4.py" layers 2>&1 | grep -E "dc_conv1|conv2_1|conv2_4|conv2_3|conv2_2" | cut -c1-120
 done
