@@ -257,6 +257,24 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
         for (int j = 0; j < G::kUS; ++j)
             if (j < G::kUS - 1 || wave < G::kUWaves) pwc::dma_b128_so(rs, base + j * kThreads * 16, u_off, j * u_step);
     };
+    // the same, one instruction at a time (PWC_W4_DMASPREAD: one LDS-DMA per MFMA shadow instead of all seven in two)
+    pwc::v4i32 rs_r, rs_u;
+    unsigned base_r = 0, base_u = 0;
+    auto setup_dma = [&](int k) {
+        const int c0 = (k + 3) * kCK;
+        rs_r = pwc::make_rsrc(xb + (int64_t)min(c0, Cin - 1) * plane, max(0, min(kCK, Cin - c0)) * plane * 4);
+        base_r = __builtin_amdgcn_readfirstlane(lds0 + ((k + 3) % 3) * G::kSlot * 4 + 4 + wave * 1024);
+        rs_u = pwc::make_rsrc(ug + (int64_t)min(k + 2, nchunks - 1) * uchunk, k + 2 < nchunks ? ubytes : 0);
+        base_u = __builtin_amdgcn_readfirstlane(lds0 + (((k + 2) % 3) * G::kSlot + G::kRawFloats) * 4 + wave * 1024);
+    };
+    auto dma_piece = [&](int t) {                        // t = 0 .. kRS + kUS - 1 in issue order (raw first)
+        if (t < G::kRS) {
+            if (t < G::kRS - 1 || wave < G::kRawWaves) pwc::dma_b128(rs_r, base_r + t * kThreads * 16, raw_off[t]);
+        } else {
+            const int j = t - G::kRS;
+            if (j < G::kUS - 1 || wave < G::kUWaves) pwc::dma_b128_so(rs_u, base_u + j * kThreads * 16, u_off, j * u_step);
+        }
+    };
     // VMEM operations of one group {raw(m + 1), U(m)} issued by THIS wave (wave-uniform; the counted waits need immediates)
     const int n_grp = G::kRS - (wave < G::kRawWaves ? 0 : 1) + G::kUS - (wave < G::kUWaves ? 0 : 1);
     constexpr int kN0 = G::kRS + G::kUS;
@@ -299,6 +317,15 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
     // operands are in registers behind the barrier), then columns 0, 1 of chunk k.  Phase ph also makes V column ph of this chunk and
     // the row transforms of patch rows 2 ph, 2 ph + 1 of the next chunk (24 VALU behind one MFMA), and reads the U groups of column ph.
     // PAR = parity of the chunk: column s of the running sequence of columns uses V buffer s & 1.
+    // All seven pieces in two MFMA shadows (as the round-2 kernels do): dc_conv1 1611 us; one piece behind every MFMA 1522, every second 1495,
+    // every fourth 1491 us
+    // (tools/wino4_exp.sh; the issuing wave stalls 60-185 cycles per piece, and in one long stall the partner wave alone cannot
+    // keep the pipe busy).
+#ifndef PWC_W4_DMASTRIDE
+#define PWC_W4_DMASTRIDE 4
+#endif
+    constexpr int kDmaStride = PWC_W4_DMASTRIDE;
+    static_assert((G::kRS + G::kUS - 1) * kDmaStride + 1 < 36, "the pieces of a group fit one iteration");
     auto iteration = [&](int k, float (&wc)[6][3], float (&wn)[6][3], auto par_tag) {
         constexpr int PAR = decltype(par_tag)::value;
         if (!(PWC_W4_EXP & 16)) {
@@ -326,8 +353,11 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
                 else        PWC_W4P_MFMA(cbl, 6 * jj + i, ucur[cbl][(p >> 2) - gb][p & 3], v0[i]);
                 // ---- in the shadow of this MFMA ----------------------------------------------------------------------
                 if (m == 0 && !(PWC_W4_EXP & 32)) { load_row(rnext, 2 * ph, da); load_row(rnext, 2 * ph + 1, db); }
-                if (ph == 0 && m == 1 && !(PWC_W4_EXP & 4)) issue_raw(k + 3);
-                if (ph == 0 && m == 2 && !(PWC_W4_EXP & 4)) issue_u(k + 2);
+                if (!(PWC_W4_EXP & 4)) {                        // LDS-DMA of {raw(k+3), U(k+2)}: ONE piece per kDmaStride MFMAs
+                    if (ph == 0 && m == 0) setup_dma(k);
+                    const int t = 12 * ph + m - 1;
+                    if (t >= 0 && t % kDmaStride == 0 && t / kDmaStride < G::kRS + G::kUS) dma_piece(t / kDmaStride);
+                }
                 if (m == 4) {                                   // V column ph of THIS chunk (consumed by the next phase) + two row transforms
                     const float col[6] = {wc[0][ph], wc[1][ph], wc[2][ph], wc[3][ph], wc[4][ph], wc[5][ph]};
                     const bool dst_v1 = (PAR + ph) & 1;
