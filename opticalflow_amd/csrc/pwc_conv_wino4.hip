@@ -42,16 +42,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 512;
 constexpr int kCK = 4;               // input channels per chunk = K of one MFMA
-constexpr int kGW = 64;              // output columns of a tile group (16 tiles of 4)
-constexpr int kRowP = 18;            // 16-byte pieces per staged row: global columns ox0 - 4 .. ox0 + 67
-constexpr int kRawW = 4 * kRowP;     // 72 floats; the row lands ONE float to the right of a 16-byte LDS boundary, so that global
-                                     // column ox0 - 1 (the first patch column) sits at index 4: every patch row is 16-byte aligned
+// A tile group is sixteen 4x4 tiles: one row of 16 (GW = 64 output columns x 4 rows) or, for narrow maps (the 14x32 lattice images of
+// dc_conv4), two rows of 8 (GW = 32 columns x 8 rows).  A staged row holds global columns ox0 - 4 .. ox0 + GW + 3 as 16-byte pieces and
+// lands ONE float to the right of a 16-byte LDS boundary, so that global column ox0 - 1 (the first patch column) sits at index 4:
+// every patch row is 16-byte aligned.
 constexpr unsigned kOOB = 0x80000000u;
 
-template <int CB, int TG>
+template <int CB, int TG, int GW = 64>
 struct Geo4 {
     static_assert(CB * TG == 8, "eight waves");
-    static constexpr int kRows = 4 * TG + 2;
+    static_assert(GW == 64 || GW == 32, "tile-group width");
+    static constexpr int kGW = GW;
+    static constexpr int kTC = GW / 4;                                // tiles per tile row of a group (16 or 8)
+    static constexpr int kGH = 4 * (16 / kTC);                        // output rows of a group (4 or 8)
+    static constexpr int kRowP = (GW + 8) / 4;                        // 16-byte pieces per staged row (18 or 10)
+    static constexpr int kRawW = 4 * kRowP;                           // 72 or 40 floats
+    static constexpr int kRows = kGH * TG + 2;
     static constexpr int kPP = (kRows * kRowP + 15) / 16 * 16;        // pieces per staged channel, padded: planes are multiples of 64 floats
     static constexpr int kPlane = 4 * kPP;
     static constexpr int kRawPieces = kCK * kPP;
@@ -175,11 +181,12 @@ __device__ __forceinline__ void bt3_row(const float (&d)[6], float (&t)[3]) {   
     asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]));
 }
 
-template <int CB, int TG, int HJ>
+template <int CB, int TG, int GW, int HJ>
 __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                                             float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
                                             int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
-    using G = Geo4<CB, TG>;
+    using G = Geo4<CB, TG, GW>;
+    constexpr int kRowP = G::kRowP, kRawW = G::kRawW;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 3 x [raw | U]
 
     const int tid = threadIdx.x;
@@ -210,8 +217,8 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int cb0 = co0 + grp * G::kCoutT;
-    const int ox0 = tx * kGW;
-    const int oy0 = ty * (4 * TG);
+    const int ox0 = tx * G::kGW;
+    const int oy0 = ty * (G::kGH * TG);
     const int plane = H * W;
 
     // ---- per-lane LDS-DMA source offsets -------------------------------------------------------------
@@ -286,8 +293,9 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
     };
 
 
-    // this lane's patch inside a raw slot: channel kq, rows 4 tgi .. 4 tgi + 5, columns 4 n .. 4 n + 5 (+ 4: see kRawW)
-    const int poff = kq * G::kPlane + (4 * tgi) * kRawW + 4 + 4 * n;
+    // this lane's tile inside its group: tile row n / kTC, tile column n % kTC; its patch inside a raw slot: channel kq, rows
+    // GH tgi + 4 tr .. + 5, columns 4 tc .. 4 tc + 5 (+ 4: the row lands one float to the right of a 16-byte boundary)
+    const int poff = kq * G::kPlane + (G::kGH * tgi + 4 * (n / G::kTC)) * kRawW + 4 + 4 * (n % G::kTC);
     // this lane's U column inside a slot's U image: [g][k = kq][cout = 32 cg2 + 16 cbl + n][4]
     const int uoff = G::kRawFloats + (kq * G::kCoutT + 32 * cg2 + n) * 4;
     constexpr int kUG = kCK * G::kCoutT * 4;              // floats per position group g
@@ -456,7 +464,7 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
         }
     }
     __syncthreads();
-    const int oyl = oy0 + 4 * tgi, ox = ox0 + 4 * (lane_e & 15);
+    const int oyl = oy0 + G::kGH * tgi + 4 * ((lane_e & 15) / G::kTC), ox = ox0 + 4 * ((lane_e & 15) % G::kTC);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int co = cb0 + 32 * cg2 + 16 * HJ + 4 * (lane_e >> 4) + c;
@@ -483,16 +491,16 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
     }
 }
 
-template <int CB, int TG>
+template <int CB, int TG, int GW>
 __global__ void __launch_bounds__(kThreads, 1)
 conv3x3_wino4p_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                       float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
                       int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
     // the position half is wave-uniform: two specialisations of the body, every index inside is a compile-time constant
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 1)
-        wino4p_body<CB, TG, 1>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
+        wino4p_body<CB, TG, GW, 1>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
     else
-        wino4p_body<CB, TG, 0>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
+        wino4p_body<CB, TG, GW, 0>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
 }
 
 // Inverse of L nested PWC_CONV_SPLIT2 stores (see pwc_hip.h): one thread per four output pixels of a row; the four come from four
@@ -521,24 +529,32 @@ lattice_unsplit_kernel(const float *__restrict__ x, float *__restrict__ y, int C
 
 inline int cout_padded4(int Cout) { return (Cout + 31) / 32 * 32; }
 
-template <int CB, int TG>
+template <int CB, int TG, int GW>
 int launch_wino4(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout,
                  int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups, int split2) {
-    using G = Geo4<CB, TG>;
-    constexpr int kSmemAttr = G::kSmemBytes > 8 * 64 * 64 * 4 ? G::kSmemBytes : 8 * 64 * 64 * 4;
+    using G = Geo4<CB, TG, GW>;
+    constexpr int kSmemP = G::kSmemBytes > 8 * 64 * 64 * 4 ? G::kSmemBytes : 8 * 64 * 64 * 4;       // rings, or the 128 KiB of the final exchange
     static pwc::LdsAttrOnce once;
-    if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino4p_kernel<CB, TG>), kSmemAttr, "conv3x3_wino4p_kernel"))
+    if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino4p_kernel<CB, TG, GW>), kSmemP, "conv3x3_wino4p_kernel"))
         return rc;
     const int CoutP = cout_padded4(Cout);
-    const int tiles_x = (W + kGW - 1) / kGW, tiles_y = (H + 4 * TG - 1) / (4 * TG);
+    const int tiles_x = (W + GW - 1) / GW, tiles_y = (H + G::kGH * TG - 1) / (G::kGH * TG);
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
     if (nblk * ngroups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
-    constexpr int kSmemP = G::kSmemBytes > 8 * 64 * 64 * 4 ? G::kSmemBytes : 8 * 64 * 64 * 4;       // rings, or the 128 KiB of the final exchange
-    hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG>), dim3((unsigned)(nblk * ngroups)), dim3(kThreads), kSmemP, st,
+    hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG, GW>), dim3((unsigned)(nblk * ngroups)), dim3(kThreads), kSmemP, st,
                        x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, (int)nblk, ngroups, split2);
-    pwc::note_kernel("conv3x3_wino4p_kernel", CB, TG, 1, 1, 1, 0);
+    pwc::note_kernel("conv3x3_wino4p_kernel", CB, TG, GW, 1, 1, 0);
     return pwc::check_launch("conv3x3_wino4p_kernel");
 }
+
+// Tile-group width for a map of W columns: 64 unless that leaves the groups under 85 % full and 32 does better (the 14x32 lattice images of
+// dc_conv4: 0.5 vs 1.0)
+inline int wino4_gw(int W) {
+    const double f64 = (double)W / ((W + 63) / 64 * 64), f32 = (double)W / ((W + 31) / 32 * 32);
+    return (f64 < 0.85 && f32 > f64) ? 32 : 64;
+}
+// rows of a map covered by the launch with `th`-row workgroups, as a fraction
+inline double wino4_row_fill(int H, int th) { return (double)H / ((H + th - 1) / th * th); }
 
 }  // namespace
 
@@ -554,18 +570,19 @@ extern "C" int pwc_conv3x3_wino4_preferred(int B, int Cin, int H, int W, int Cou
     static const int knob = [] { const char *e = getenv("PWC_CONV_WINO4"); return (e && *e) ? atoi(e) : 1; }();
     if (!knob) return 0;
     const int n32 = cout_padded4(Cout) / 32;
-    const int tiles_x = (W + kGW - 1) / kGW;
-    // every launch the layer splits into must cover the chip: the 64-cout launch (8-row tile groups) and, for an odd number of
-    // 32-cout blocks, the 32-cout one (16-row groups) -- conv3_2 (96 couts @56x128) fails on the latter (128 workgroups, x0.94)
+    const int gw = wino4_gw(W), gh = gw == 64 ? 4 : 8;                 // a tile group is gh rows x gw columns
+    const int tiles_x = (W + gw - 1) / gw;
+    // every launch the layer splits into must cover the chip: the 64-cout launch (two tile groups per workgroup) and, for an odd number
+    // of 32-cout blocks, the 32-cout one (four groups) -- conv3_2 (96 couts @56x128) fails on the latter (128 workgroups, x0.94)
     if (n32 >= 2) {
-        const int ty = (H + 7) / 8;
-        if ((double)H / (ty * 8) < 0.85 || (int64_t)B * tiles_x * ty * (n32 / 2) < 200) return 0;
+        const int th = 2 * gh;
+        if (wino4_row_fill(H, th) < 0.85 || (int64_t)B * tiles_x * ((H + th - 1) / th) * (n32 / 2) < 200) return 0;
     }
     if (n32 & 1) {
-        const int ty = (H + 15) / 16;
-        if ((double)H / (ty * 16) < 0.85 || (int64_t)B * tiles_x * ty < 200) return 0;
+        const int th = 4 * gh;
+        if (wino4_row_fill(H, th) < 0.85 || (int64_t)B * tiles_x * ((H + th - 1) / th) < 200) return 0;
     }
-    return (double)W / (tiles_x * kGW) >= 0.85;
+    return (double)W / (tiles_x * gw) >= 0.85;
 }
 
 extern "C" int64_t pwc_conv3x3_wino4_packed_bytes(int Cin, int Cout) {
@@ -604,11 +621,19 @@ extern "C" int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *
         PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: PWC_CONV_SPLIT2 needs even H, W %% 8 == 0 and an even batch stride");
     const int n32 = cout_padded4(Cout) / 32;
     // 64-cout workgroups (4 cout blocks x 2 tile groups) for as many pairs of 32 as there are, one 32-cout launch (2 x 4) for an odd rest
-    if (n32 >= 2)
-        if (const int rc = launch_wino4<4, 2>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2))
-            return rc;
-    if (n32 & 1)
-        return launch_wino4<2, 4>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2);
+    if (wino4_gw(W) == 64) {
+        if (n32 >= 2)
+            if (const int rc = launch_wino4<4, 2, 64>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2))
+                return rc;
+        if (n32 & 1)
+            return launch_wino4<2, 4, 64>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2);
+    } else {
+        if (n32 >= 2)
+            if (const int rc = launch_wino4<4, 2, 32>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2))
+                return rc;
+        if (n32 & 1)
+            return launch_wino4<2, 4, 32>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2);
+    }
     return PWC_OK;
 }
 

@@ -187,6 +187,14 @@ class PwcPlan:
                     if self.ctx_lattice:                      # dc_conv2 / dc_conv3 run as dilation-1 layers on the lattices
                         for key in ("dc_conv2.0", "dc_conv3.0"):
                             self.wino4_packed[key] = ops.pack_conv3x3_wino4(self.p[key + ".weight"])
+                        # dc_conv4 (128 -> 96 on 64B images of h/8 x w/8, e.g. 14x32): its first 64 couts fill F(4x4)'s 32-column tile
+                        # groups, a 32-cout F(4x4) launch (32-row workgroups) would be half empty -> those couts stay on F(2x2)
+                        w4 = self.p["dc_conv4.0.weight"]
+                        self.dc4_split = bool(w4.shape[0] == 96 and ops.conv3x3_wino4_preferred(64 * B, w4.shape[1], h2 // 8, w2 // 8, 64))
+                        if self.dc4_split:
+                            self.wino4_packed["dc_conv4.0[:64]"] = ops.pack_conv3x3_wino4(w4[:64].contiguous())
+                            self.wino_packed["dc_conv4.0[64:]"] = ops.pack_conv3x3_wino(w4[64:].contiguous())
+                            self.dc4_bias = (self.p["dc_conv4.0.bias"][:64].contiguous(), self.p["dc_conv4.0.bias"][64:].contiguous())
                 for key, b_, cin, co, l in geo:
                     h, w = self.size[l]
                     if key in self.wino_packed and ops.conv3x3_wino4_preferred(b_, cin, h, w, co):
@@ -388,7 +396,16 @@ class PwcPlan:
         w4("dc_conv1", self.arena[2], self.ctx[0], True)          # [B,565,H,W]      -> 4B  x [128,H/2,W/2]   (lattices of dilation 2)
         w4("dc_conv2", self.ctx[0], self.ctx[1], True)            # dilation 2 = 1 on those -> 16B x [128,H/4,W/4]
         w4("dc_conv3", self.ctx[1], self.ctx[2], True)            # dilation 4 = 1          -> 64B x [128,H/8,W/8]
-        self._conv("dc_conv4", self.ctx[2], self.ctx[3], dilation=1)        # dilation 8 = 1 on the dilation-8 lattices
+        if getattr(self, "dc4_split", False):                     # dilation 8 = 1 on the dilation-8 lattices: 64 couts F(4x4) + 32 couts F(2x2)
+            x4 = self.ctx[2]
+            macs = x4.shape[0] * 96 * x4.shape[1] * 9 * x4.shape[2] * x4.shape[3]
+            self.conv_macs["direct"] += macs
+            self.conv_macs["executed"] += macs * 2 // 3 * 36 // 144 + macs // 3 * 16 // 36
+            ops.conv3x3_wino4(x4, self.wino4_packed["dc_conv4.0[:64]"], self.dc4_bias[0], 64, leaky_slope=LEAKY, out=self.ctx[3][:, :64])
+            ops.conv3x3_wino(x4, self.wino_packed["dc_conv4.0[64:]"], self.dc4_bias[1], 32, leaky_slope=LEAKY, out=self.ctx[3][:, 64:],
+                             workspace=self.workspace)
+        else:
+            self._conv("dc_conv4", self.ctx[2], self.ctx[3], dilation=1)
         self._conv("dc_conv5", self.ctx[3], self.ctx4_lat, dilation=2)      # dilation 16 = 2 on them
         ops.lattice_unsplit(self.ctx4_lat, B, 3, out=self.ctx[4])
         self._conv("dc_conv6", self.ctx[4], self.ctx[5], dilation=1)

@@ -1098,3 +1098,21 @@ def test_forward_context_lattice_layout_matches_plain_layout(gpu_device, monkeyp
     with torch.no_grad():
         ref = O.pwc_forward(sd, xc[3:4])
     assert O.epe(out["1"][3:4].cpu(), ref) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(8, 128, 64, 14, 32), (2, 40, 32, 30, 32), (3, 24, 96, 17, 28)])
+def test_conv3x3_winograd4_narrow_maps(gpu_device, case):
+    """Maps of <= 32 columns (the 14x32 lattice images dc_conv4 runs on in the lattice-major context network) take the F(4x4) kernel's
+    second geometry: tile groups of 2 x 8 tiles (8 rows x 32 columns) instead of 1 x 16.  Same budget as the wide form."""
+    from opticalflow_amd import ops, _lib
+    B, cin, cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1)
+    got = ops.conv3x3_wino4(x.to(gpu_device), ops.pack_conv3x3_wino4(w.to(gpu_device)), b.to(gpu_device), cout).cpu()
+    kern = _lib.load().pwc_last_conv_kernel().decode()
+    assert "wino4p" in kern and ", 32," in kern, kern              # <CB, TG, GW = 32, ...>
+    assert (got.double() - ref).abs().max().item() <= 1e-6 * (cin * 9) ** 0.5

@@ -24,9 +24,9 @@ def short(n):
     m = (re.search(r"conv3x3_f16w8_kernel<(\d+), (\d+)", n) or re.search(r"conv3x3_f16w8_kernelILi(\d+)ELi(\d+)E", n))
     if m:
         return "f16w8<MT%s,D%s>" % m.groups()
-    m = re.search(r"conv3x3_wino4_kernel<(\d+), (\d+)>", n) or re.search(r"conv3x3_wino4_kernelILi(\d+)ELi(\d+)E", n)
+    m = re.search(r"conv3x3_wino4p?_kernel<(\d+), (\d+)(?:, (\d+))?>", n) or re.search(r"conv3x3_wino4p?_kernelILi(\d+)ELi(\d+)E(?:Li(\d+)E)?", n)
     if m:
-        return "wino4<CB%s,TG%s>" % m.groups()
+        return "wino4<CB%s,TG%s%s>" % (m.group(1), m.group(2), ",GW32" if m.group(3) == "32" else "")
     m = re.search(r"conv3x3_wino(8r?)_kernel<(\d+)>", n) or re.search(r"conv3x3_wino(8r?)_kernelILi(\d+)E", n)
     if m:
         return "wino%s<MT%s>" % m.groups()
