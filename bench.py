@@ -519,6 +519,13 @@ def main():
         with torch.no_grad():
             ref = O.pwc_forward(sd_cpu, xs)
         result["epe_vs_cpu_oracle_64x128"] = float("%.3e" % O.epe(net(xs.to(dev)).cpu(), ref))
+        if (H, W) == (448, 1024) and args.conv_backend == "hip":
+            # ... and item 0 of the MEASURED batch (the graph replay's own output at the headline geometry: the routes a 64x128
+            # input never takes -- F(4x4), lattice-major context network, split-K) against the oracle on the same pair
+            torch.set_num_threads(host_cores())
+            with torch.no_grad():
+                ref0 = O.pwc_forward(sd_cpu, x[:1].cpu())
+            result["epe_vs_cpu_oracle_headline_item0"] = float("%.3e" % O.epe(net(x)[:1].cpu(), ref0))
         if world == 1 and fp32 and args.conv_backend == "hip" and not args.no_graph:
             # side measurement, not the metric: the same workload through the half-precision plan (BASELINE configs[3]
             # per-GPU shard), timed the same way after the fp32 region; `python bench.py --precision fp16` is the full line

@@ -63,6 +63,24 @@ def test_abi_argument_errors_without_gpu():
     assert pref(16, 341, 14, 32, 128, 1) == 0 and wsb(16, 341, 14, 32, 128, 1) == 0                 # level 5 (64 tiles) stays on the direct kernel
     assert wsb(16, 565, 112, 256, 128, 1) == 0                                                    # a full grid does not split
     assert pref(16, 96, 112, 256, 64, 16) == 0 and pref(1, 565, 112, 256, 128, 1) == 1            # 7x16 lattices; batch 1 at level 2
+    # Winograd F(4x4,3x3) (round 3): packed size = 36 / 9 of the filter with Cout padded to 32 and Cin to 4; the measured rule; argument errors
+    assert lib.pwc_conv3x3_wino4_packed_bytes(565, 128) == 142 * 36 * 4 * 128 * 4 and lib.pwc_conv3x3_wino4_packed_bytes(0, 8) == -1
+    assert lib.pwc_conv3x3_wino4_packed_bytes(5, 7) == 2 * 36 * 4 * 32 * 4
+    p4 = lib.pwc_conv3x3_wino4_preferred
+    assert p4(16, 565, 112, 256, 128, 1) == 1 and p4(16, 373, 112, 256, 96, 1) == 1 and p4(64, 128, 56, 128, 128, 1) == 1
+    assert p4(16, 405, 56, 128, 96, 1) == 0          # its 32-cout launch would have 128 workgroups
+    assert p4(16, 128, 112, 256, 128, 2) == 0        # dilated layers: F(2x2) on lattices, or the lattice-major layout (engine)
+    assert p4(1, 565, 112, 256, 128, 1) == 0         # batch 1 does not fill the chip
+    assert p4(1024, 128, 14, 32, 64, 1) == 1         # narrow maps: 2 x 8 tile groups
+    assert p4(16, 16, 224, 512, 16, 1) == 0 and p4(16, 64, 112, 254, 64, 1) == 0
+    vp = ctypes.c_void_p
+    assert lib.pwc_conv3x3_wino4_fwd(None, vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 1, 0, 0.0, 32 * 512, 32 * 512, None) == -1
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 62, 32, 1, 0, 0.0, 32 * 496, 32 * 496, None) == -2   # W % 4
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 2, 0, 0.0, 32 * 512, 32 * 512, None) == -2   # dilation
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4100), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 1, 0, 0.0, 32 * 512, 32 * 512, None) == -3   # alignment
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 7, 64, 32, 1, 32, 0.0, 32 * 448, 32 * 448, None) == -1  # SPLIT2: odd H
+    assert lib.pwc_lattice_unsplit_f32(vp(4096), vp(4096), 1, 8, 4, 5, 1, 8 * 8 * 10, None) == -3                                               # W % 4 after unsplit
+    assert lib.pwc_lattice_unsplit_f32(vp(4096), vp(4096), 1, 8, 4, 6, 0, 8 * 8 * 12, None) == -1
     # split filters: 16 couts per 32-row tile -> twice the rows beyond Cout = 16, the plain size up to there (ABI v8)
     assert lib.pwc_conv3x3_f16_packed_bytes_split(64, 32) == 2 * lib.pwc_conv3x3_f16_packed_bytes(64, 32)
     assert lib.pwc_conv3x3_f16_packed_bytes_split(64, 9) == lib.pwc_conv3x3_f16_packed_bytes(64, 9)
