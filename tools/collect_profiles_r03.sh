@@ -30,6 +30,7 @@ say "kernel traces + timelines"
 bash "$ROOT/tools/collect_timelines.sh" > /dev/null 2>&1
 cp "$ROOT/gpurun_out/tl/timeline_fp32.txt" "$OUT/forward_timeline_b16.txt"
 cp "$ROOT/gpurun_out/tl/timeline_fp16.txt" "$OUT/f16_forward_timeline_b16.txt"
+cp "$ROOT/gpurun_out/tl/timeline_fp16-strict.txt" "$OUT/f16s_forward_timeline_b16.txt"
 cp "$ROOT/gpurun_out/tl/kernel_stats_fp32.csv" "$OUT/kernel_stats_bench_b16.csv"
 cp "$ROOT/gpurun_out/tl/kernel_stats_fp16.csv" "$OUT/f16_kernel_stats_bench_b16.csv"
 
@@ -67,6 +68,13 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ
   rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_wino4.py" pmc > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino4 $c >> "$OUT/pmc_summary.txt"
   python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_wino8r $c >> "$OUT/pmc_summary.txt"; rm -rf "$OUT/q"
+done
+# fp16 dc_conv1: matrix-pipe busy cycles and the clock the chip held (GRBM_GUI_ACTIVE / 8 XCDs / duration), MI355X guide "DVFS give-back"
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA; do
+  PWC_BENCH_F16_ONLY=1 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_conv_f16.py" dc_conv1 > /dev/null 2>&1
+  python3 "$ROOT/tools/pmc_avg.py" "$OUT/q" conv3x3_f16 $c >> "$OUT/pmc_summary.txt"
+  [ "$c" = GRBM_GUI_ACTIVE ] && cp "$(find "$OUT/q" -name "*kernel_trace.csv" | head -1)" "$OUT/f16_grbm_trace.csv"
+  rm -rf "$OUT/q"
 done
 for c in SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM; do
   PWC_BENCH_LEVELS=2 rocprofv3 --kernel-trace --pmc $c -d "$OUT/q" -o p --output-format csv -- python3 "$ROOT/tools/bench_warpcorr.py" > /dev/null 2>&1

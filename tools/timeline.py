@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per-launch timeline of ONE forward of bench.py.
 
-usage: tools/timeline.py <kernel_trace.csv> [--full] [--min-grid=N] [--fp32]
+usage: tools/timeline.py <kernel_trace.csv> [--full] [--min-grid=N] [--fp32 [--strict]]
 --fp32: the trace also holds fp16 forwards (bench.py's fp16_same_workload leg); pick the fp32 plan's forward.
+--strict (with --fp32): the fp16-strict plan, whose forward starts on the fp32 kernels and continues on the half-precision ones.
 A forward starts at the two back-to-back stride-2 launches of conv1a on the two images.
 """
 import csv
@@ -70,7 +71,7 @@ def main():
         def span(i):
             return int(rows[starts[i + 1]]["Start_Timestamp"]) - int(rows[starts[i]]["Start_Timestamp"])
         pure = [i for i in range(len(starts) - 1)
-                if not any(n.startswith("f16conv") or n.startswith("f16w8") or n in ("image_conv_s2", "pyr1_fused") for n in names[starts[i]:starts[i + 1]])]
+                if "--strict" in sys.argv or not any(n.startswith("f16conv") or n.startswith("f16w8") or n in ("image_conv_s2", "pyr1_fused") for n in names[starts[i]:starts[i + 1]])]
         best = min(span(i) for i in pure)
         i = [i for i in pure if span(i) <= 1.2 * best][-1]
         s, e = starts[i], starts[i + 1]
