@@ -227,7 +227,10 @@ corr81_kernel(const T *__restrict__ in1, const T *__restrict__ in2, T *__restric
 // Needs W % 4 == 0 and 16-byte aligned operands (the launcher falls back to corr81_kernel otherwise).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kCKd = 4;                                   // channels per chunk
-constexpr int kRing = 3;                                  // LDS slots: one consumed, two in flight (2: 76 us, 3: 65 us, 4: 75 us)
+#ifndef PWC_CORR_RING
+#define PWC_CORR_RING 3
+#endif
+constexpr int kRing = PWC_CORR_RING;                      // LDS slots: one consumed, two in flight (2: 76 us, 3: 65 us, 4: 75 us)
 constexpr int kS2Floats = kCKd * kS2Rows * kPitch;        // 2560: in2 halo tile [c][16][40]
 constexpr int kS1Floats = kCKd * kTH * kPitch;            // 1280: in1 tile      [c][8][40] (cols 32..39 unused)
 constexpr int kS2Instr = kS2Floats / 4 / 64;              // 10 wave-instructions of 64 x 16 B
@@ -404,6 +407,23 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
                 __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     pwc::uniform_ptr(src + (int64_t)c0 * plane), 0, __builtin_amdgcn_readfirstlane(min(kCKd, C - c0) * plane * 4), 0x00020000);
                 float *slot = smem + (pr_step % kRing) * kBufFloats;
+#ifdef PWC_WC_SEQ
+                // one halo pixel at a time: 8 gathers in flight instead of 16, 16 fewer live registers
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f32x2 top[kCKd], bot[kCKd];
+#pragma unroll
+                    for (int c = 0; c < kCKd; ++c) {
+                        top[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, otop[k], c * plane * 4, 0));
+                        bot[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, obot[k], c * plane * 4, 0));
+                    }
+#pragma unroll
+                    for (int c = 0; c < kCKd; ++c)
+                        slot[c * kS2Rows * kPitch + ldsoff[k]] =
+                            pwc_warp::blend4(top[c][0], top[c][1], bot[c][0], bot[c][1], wgt[k][0], wgt[k][1], wgt[k][2], wgt[k][3]);
+                    asm volatile("" ::: "memory");
+                }
+#else
                 f32x2 top[2][kCKd], bot[2][kCKd];
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
@@ -418,6 +438,7 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
                     for (int c = 0; c < kCKd; ++c)
                         slot[c * kS2Rows * kPitch + ldsoff[k]] =
                             pwc_warp::blend4(top[k][c][0], top[k][c][1], bot[k][c][0], bot[k][c][1], wgt[k][0], wgt[k][1], wgt[k][2], wgt[k][3]);
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile is in LDS before this wave reaches the barrier
                 ++pr_step;
                 if (++pr_chunk == nchunks) { pr_chunk = 0; pr_tile += stride; }

@@ -29,20 +29,31 @@
 #define PWC_STREAM_DMA pwc::dma_b128
 #endif
 
+#ifndef PWC_STREAM_EXP
+#define PWC_STREAM_EXP 0           // timing experiments (results invalid): 1 = consumers skip the arithmetic, 2 = every fetch reads chunk 0, 4 = no LDS-DMA inside the loop
+#endif
+
 namespace {
 
 using pwc::leaky;
 
 constexpr int kCK = 4;                  // channels per chunk
-constexpr int kRing = 3;                // 72 KiB -> two workgroups per CU (a 4th slot measured slower: one WG/CU)
+#ifndef PWC_STREAM_RING
+#define PWC_STREAM_RING 3
+#endif
+constexpr int kRing = PWC_STREAM_RING;  // 3 slots of 24 KiB (8-row tiles) -> two workgroups per CU; the counted vmcnt has 6 bits, so
+                                        // an 8-row tile (26 VMEM instructions per chunk) cannot keep more than two chunks in flight
 constexpr int kTW = 128;
 constexpr int kPitch = kTW + 8;         // floats: cols x0-4 .. x0+131
 constexpr int kQuads = kPitch / 4;      // 34 pieces per row
 constexpr int kHeadWRow = 20;           // global: {co0: 9 taps, 0, co1: 9 taps, 0} per channel; LDS: [tap][co] + 2 zeros
 constexpr int kUpWRow = 32;             // global: nn layout [ci][co][4][4]; LDS: [ky*4+kx][co]
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOOB = 0x80000000u;
-static_assert(kRing == 3, "the loader's counted wait assumes exactly one younger chunk in flight");
+static_assert(kRing >= 3 && kRing <= 5, "ring depth");
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // Tile geometry.  TH rows x 128 columns per workgroup; KS consumer groups of TH*32 threads share the tile, group k
 // accumulating channels k*(4/KS).. of every chunk (partial sums meet in LDS after the last chunk).  <8,1> is the
@@ -78,7 +89,7 @@ template <int MODE, typename G>
 __device__ __forceinline__ void issue(const float *xb, const float *hw, const float *uw, int chunk, int Cin, int plane,
                                       float *buf, const unsigned (&off)[G::kTileInstr], const unsigned (&woff)[4]) {
     constexpr int kInstr = G::kInstr;
-    const int c0 = chunk * kCK;
+    const int c0 = (PWC_STREAM_EXP & 2) ? 0 : chunk * kCK;
     const int cvalid = min(kCK, Cin - c0);
     const pwc::v4i32 r = pwc::make_rsrc(xb + (int64_t)c0 * plane, cvalid * plane * 4);
     const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(buf));
@@ -163,10 +174,15 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
         for (int k = 0; k < kRing - 1; ++k)
             if (k < nchunks) issue<MODE, G>(xb, hw, uw, k, Cin, plane, smem + k * kBuf, off, woff);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            if (chunk + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kVmem) : "memory");   // kRing == 3
-            else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // chunk `chunk` has landed; up to kRing - 2 younger ones stay in flight
+            constexpr bool kRingOk = (kRing - 2) * kVmem <= 63;          // vmcnt is a 6-bit counter; launch_cfg refuses the others
+            const int younger = min(kRing - 2, nchunks - 1 - chunk);
+            if (younger >= 3)      wait_vm<(kRing >= 5 && kRingOk ? 3 : 0) * kVmem>();
+            else if (younger == 2) wait_vm<(kRing >= 4 && kRingOk ? 2 : 0) * kVmem>();
+            else if (younger == 1) wait_vm<kVmem>();
+            else                   wait_vm<0>();
             __builtin_amdgcn_s_barrier();      // consumers may read slot chunk%3; they are done with (chunk-1)%3
-            if (chunk + kRing - 1 < nchunks)
+            if (chunk + kRing - 1 < nchunks && !(PWC_STREAM_EXP & 4))
                 issue<MODE, G>(xb, hw, uw, chunk + kRing - 1, Cin, plane, smem + ((chunk + kRing - 1) % kRing) * kBuf, off, woff);
         }
         if constexpr (KS > 1) {            // the two barriers of the consumers' reduction
@@ -191,17 +207,22 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
         const float *cur = smem + (chunk % kRing) * kBuf;
         // channels past Cin in the last chunk: tile AND taps were range-checked to 0, so they add exactly 0
 #pragma unroll
-        for (int cc = 0; cc < G::kCPerGroup; ++cc) {
+        for (int cc = 0; cc < ((PWC_STREAM_EXP & 1) ? 0 : G::kCPerGroup); ++cc) {
             const int c = grp * G::kCPerGroup + cc;
-            const float *t = cur + (c * kRows + ty) * kPitch + 4 * tx + 3;     // window col -1
+            // window columns -1 .. 4 of the thread's 4 pixels = staged floats 4 tx + 3 .. 4 tx + 8: three ALIGNED 16-byte reads
+            // (conflict-free, 4 LDS cycles each).  Reading exactly the six floats (b32 + b128 + b32) is what the first version
+            // asked for; the compiler merged them into three ds_read2_b32 at a 16-byte lane stride = 4-way bank conflicts on
+            // the 32-bank path, 96 LDS cycles per row instead of 12 -- the kernel was LDS-bound at 0.35 of HBM (round-3 ablation).
+            const float *t = cur + (c * kRows + ty) * kPitch + 4 * tx;
             float v[3][6];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const float *row = t + r * kPitch;
-                const float4 m = *reinterpret_cast<const float4 *>(row + 1);
-                v[r][0] = row[0];
-                v[r][1] = m.x; v[r][2] = m.y; v[r][3] = m.z; v[r][4] = m.w;
-                v[r][5] = row[5];
+                const f32x4 *row = reinterpret_cast<const f32x4 *>(t + r * kPitch);
+                f32x4 l = row[0], m = row[1], h = row[2];
+                asm volatile("" : "+v"(l), "+v"(h));          // keep the edge reads whole: narrowed to b64 / b32 they conflict again
+                v[r][0] = l[3];
+                v[r][1] = m[0]; v[r][2] = m[1]; v[r][3] = m[2]; v[r][4] = m[3];
+                v[r][5] = h[0];
             }
             if constexpr (MODE & MODE_HEAD) {
                 const float4 *wq = reinterpret_cast<const float4 *>(cur + kHeadWOff + c * kHeadWRow);   // LDS broadcast
@@ -331,6 +352,7 @@ int launch_cfg(const float *x, int B, int Cin, int H, int W, int64_t bsx,
                const float *hw, const float *hbias, const float *residual, float *hy, int64_t bshy, int64_t bsr,
                float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
     using G = Cfg<TH, KS>;
+    if constexpr ((kRing - 2) * G::kVmem > 63) return PWC_EUNSUPPORTED;      // experiment builds with a deeper ring
     const int tiles_x = (W + kTW - 1) / kTW;
     const int tiles_y = (H + TH - 1) / TH;
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
@@ -359,10 +381,11 @@ int launch(const float *x, int B, int Cin, int H, int W, int64_t bsx,
            float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
     const int64_t nblk8 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8);
     int cfg = stream_cfg_override();
-    if (cfg != 81 && cfg != 42 && cfg != 44) cfg = nblk8 < 256 ? 44 : 81;
+    if (cfg != 81 && cfg != 42 && cfg != 44 && cfg != 41) cfg = nblk8 < 256 ? 44 : 81;
 #define PWC_STREAM_GO(TH, KS) return launch_cfg<MODE, TH, KS>(x, B, Cin, H, W, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky, uw, ubias, uy, bsuy, st)
     if (cfg == 44) PWC_STREAM_GO(4, 4);
     if (cfg == 42) PWC_STREAM_GO(4, 2);
+    if (cfg == 41) PWC_STREAM_GO(4, 1);
     PWC_STREAM_GO(8, 1);
 #undef PWC_STREAM_GO
 }
