@@ -55,13 +55,7 @@ __device__ __forceinline__ void *uniform_ptr(const void *p) {
     return reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
 }
 
-// M16 = 1: geometry of conv3x3_mfma16_kernel.  There the four lane quarters of one LDS read sit on four consecutive channels, so the
-// channel strides of both LDS images are padded to 16 mod 32 floats: quarters 0/1 (and 2/3) of a 32-lane read group then cover all 32
-// banks instead of colliding pairwise (round 3: SQ_LDS_BANK_CONFLICT was 50 % of the kernel's LDS cycles).
-// S = 2: a staged row keeps its even columns first, then its odd ones, so that the lanes of a tap read consecutive floats instead of
-// every second one (2-way conflicts on every B read, 38 % of the LDS cycles of the stride-2 layers); the dword LDS-DMA places any
-// element anywhere, so only the per-lane source offsets and the read addresses know.
-template <int MT, int NT, int S, int D, int TWO, int CKO = 0, int M16 = 0>
+template <int MT, int NT, int S, int D, int TWO, int CKO = 0>
 struct Geom {
     static constexpr int kCK = CKO ? CKO : (TWO ? 4 : 8);           // input channels per chunk
     static constexpr int kWPS = TWO ? 2 : 1;                        // waves per SIMD the register budget must allow
@@ -69,16 +63,13 @@ struct Geom {
     static constexpr bool kRowSep = (D >= 16);                      // stage the three ky row-sets separately
     static constexpr int kInW = (kTileW - 1) * S + 2 * D + 1;
     static constexpr int kInH = kRowSep ? 3 * kTileH : (kTileH - 1) * S + 2 * D + 1;
-    static constexpr int kCHraw = kInH * kInW;                       // floats per staged channel (flat)
-    static constexpr int kCH = M16 ? kCHraw + ((16 - kCHraw % 32) + 32) % 32 : kCHraw;     // channel stride
-    static constexpr int kEven = (kInW + 1) / 2;                     // S == 2: even columns of a row come first
+    static constexpr int kCH = kInH * kInW;                          // floats per staged channel (flat)
     static constexpr int kKyStride = kRowSep ? kTileH * kInW : D * kInW;
     static constexpr int kInElems = kCK * kCH;
     static constexpr int kInSlots = (kInElems + kThreads - 1) / kThreads;       // dword DMAs per thread per chunk
     static constexpr int kInRegion = kInSlots * kThreads;                         // floats
     static constexpr int kCoutT = 32 * MT;
-    static constexpr int kWCS = 9 * kCoutT + (M16 ? 16 : 0);                      // floats per channel of the weight slab (288 + 16 = 304 = 16 mod 32)
-    static constexpr int kWPieces = kCK * kWCS / 4;                               // 16-byte pieces per chunk
+    static constexpr int kWPieces = kCK * 9 * kCoutT / 4;                         // 16-byte pieces per chunk
     static constexpr int kWSlots = (kWPieces + kThreads - 1) / kThreads;
     static constexpr int kWRegion = kWSlots * kThreads * 4;                       // floats
     static constexpr int kBufFloats = kInRegion + kWRegion;
@@ -155,8 +146,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
         const int c = i / G::kCH;
         const int rem = i % G::kCH;
         const int r = rem / G::kInW;
-        int xx = rem % G::kInW;
-        if constexpr (S == 2) xx = xx < G::kEven ? 2 * xx : 2 * (xx - G::kEven) + 1;      // LDS position -> source column
+        const int xx = rem % G::kInW;
         int iy;
         if constexpr (G::kRowSep) {
             iy = oy0 + (r % G::kTileH) - D + (r / G::kTileH) * D;
@@ -212,7 +202,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
             issue_chunk<G>(xb, wg, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
                            in_off, w_off);
 
-        const float *rd_in = cur + kh * G::kCH + (wave * NT) * S * G::kInW + (S == 2 ? col : col * S);
+        const float *rd_in = cur + kh * G::kCH + (wave * NT) * S * G::kInW + col * S;
         const float *rd_w = cur + G::kInRegion + kh * 9 * G::kCoutT + col;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -224,7 +214,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
                 for (int mt = 0; mt < MT; ++mt) a[mt] = rd_w[(cp * 2 * 9 + tap) * G::kCoutT + mt * 32];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bv[nt] = rd_in[cp * 2 * G::kCH + ky * G::kKyStride + (S == 2 ? (kx == 1 ? G::kEven : kx / 2) : kx * D) + nt * S * G::kInW];
+                    bv[nt] = rd_in[cp * 2 * G::kCH + ky * G::kKyStride + kx * D + nt * S * G::kInW];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -277,7 +267,7 @@ conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp,
                       const float *__restrict__ residual, float *__restrict__ y,
                       int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
                       int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky) {
-    using G = Geom<1, NT, 1, 1, 1, CKT, 1>;
+    using G = Geom<1, NT, 1, 1, 1, CKT>;
     constexpr int CK = G::kCK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -308,18 +298,16 @@ conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp,
         const int rem = i % G::kCH;
         const int iy = oy0 - 1 + rem / G::kInW;
         const int ix = ox0 - 1 + rem % G::kInW;
-        const bool ok = (i < G::kInElems) && (rem < G::kCHraw) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
+        const bool ok = (i < G::kInElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
         in_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
     }
     unsigned w_off[G::kWSlots];
 #pragma unroll
     for (int j = 0; j < G::kWSlots; ++j) {
-        const int p = j * kThreads + tid;                       // 16-byte piece of the padded slab [c][304]
-        const int c = p / (G::kWCS / 4);
-        const int r = p % (G::kWCS / 4);                        // (tap, quad of couts); r >= 72: the pad
-        const int row = c * 9 + r / (G::kCoutT / 4);
-        const int q = r % (G::kCoutT / 4);
-        w_off[j] = (p < G::kWPieces && r < 9 * G::kCoutT / 4) ? (unsigned)(row * CoutP + q * 4) * 4u : kOOB;
+        const int p = j * kThreads + tid;
+        const int row = p / (G::kCoutT / 4);
+        const int q = p % (G::kCoutT / 4);
+        w_off[j] = (p < G::kWPieces) ? (unsigned)(row * CoutP + q * 4) * 4u : kOOB;
     }
 
     f32x4 acc[NT][2];
@@ -344,13 +332,13 @@ conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp,
             issue_chunk<G>(xb, wp, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
                            in_off, w_off);
         const float *rd_in = cur + kg * G::kCH + (wave * NT) * G::kInW + acol;
-        const float *rd_w = cur + G::kInRegion + kg * G::kWCS + acol;
+        const float *rd_w = cur + G::kInRegion + kg * 9 * G::kCoutT + acol;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int kq = 0; kq < CK / 4; ++kq) {
-                const float a = rd_w[kq * 4 * G::kWCS + tap * G::kCoutT];
+                const float a = rd_w[(kq * 4 * 9 + tap) * G::kCoutT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float *p = rd_in + kq * 4 * G::kCH + (nt + ky) * G::kInW + kx;
@@ -468,7 +456,7 @@ struct TileChoice16 { int nt; };
 
 template <int NT, int CKT>
 int launch16(const ConvArgs &a) {
-    using G = Geom<1, NT, 1, 1, 1, CKT, 1>;
+    using G = Geom<1, NT, 1, 1, 1, CKT>;
     static_assert(G::kSmemBytes <= 160 * 1024, "tile does not exist");
     const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
     const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
