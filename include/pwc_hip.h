@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 8
+#define PWC_ABI_VERSION 9
 
 /* element types */
 #define PWC_F32 0
@@ -183,7 +183,12 @@ int pwc_conv3x3_wino4_preferred(int B, int Cin, int H, int W, int Cout, int dila
 int pwc_conv3x3_wino4_pack(const void *w, void *up, int Cin, int Cout, void *stream);
 int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *bias, void *y,
                           int B, int Cin, int H, int W, int Cout, int dilation, unsigned flags, float leaky_slope,
-                          int64_t x_bstride, int64_t y_bstride, void *stream);
+                          int64_t x_bstride, int64_t y_bstride, void *workspace, int64_t workspace_bytes, void *stream);
+/* workspace (device, 16-byte aligned, may be NULL): pwc_conv3x3_wino4_workspace_bytes() bytes, shareable with the other convolutions'
+ * workspaces on one stream.  With it, a launch whose last round of workgroups would leave most CUs idle (n workgroups on 256 CUs cost
+ * ceil(n / 256) rounds: 896 -> 4 instead of 3.5) runs the tiles of that round as input-channel slices that fill the chip and adds the
+ * slices in a fixed order (deterministic); without it the layer runs unsplit.  Not combined with PWC_CONV_SPLIT2. */
+int64_t pwc_conv3x3_wino4_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 /* Inverse of `levels` nested PWC_CONV_SPLIT2 stores: x [B * 4^levels][C][h][w] (contiguous) -> y [B][C][h << levels][w << levels]
  * (dense planes, free batch stride); image index ((b*4 + s1)*4 + s2)... with s_i = 2 (y_i & 1) + (x_i & 1), coarsest split first. */
 int pwc_lattice_unsplit_f32(const void *x, void *y, int B, int C, int h, int w, int levels, int64_t y_bstride, void *stream);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
 LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
@@ -59,7 +59,8 @@ SIGNATURES = {
     "pwc_conv3x3_wino4_preferred": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pwc_conv3x3_wino4_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "pwc_conv3x3_wino4_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
-                                     c_int64, c_int64, c_void_p]),
+                                     c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "pwc_conv3x3_wino4_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "pwc_lattice_unsplit_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "pwc_conv2d_f16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),

@@ -203,7 +203,7 @@ extern "C" int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const voi
     if (x_bstride < (int64_t)Cin * H * W) PWC_FAIL(PWC_EINVAL, "pwc_head_upfeat_fwd: x batch stride < Cin*H*W");
     const float *xf = static_cast<const float *>(x);
     if (!pwc_conv::stream3x3_ok(B, Cin, H, W, xf, x_bstride)) {
-        pwc::set_error("pwc_head_upfeat_fwd: geometry %dx%dx%dx%d outside the streaming kernel (needs W %% 4 == 0, W >= 128)", B, Cin, H, W);
+        pwc::set_error("pwc_head_upfeat_fwd: geometry %dx%dx%dx%d outside the streaming kernel (needs W %% 4 == 0, W >= 64)", B, Cin, H, W);
         return PWC_EUNSUPPORTED;
     }
     const float *w_raw = static_cast<const float *>(head_wp) + mfma_image_floats(Cin, 2);

@@ -152,6 +152,16 @@ wino4_pack_kernel(const float *__restrict__ w, float *__restrict__ up, int Cin, 
 
 #define PWC_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 
+// Split of a launch's LAST, partial round of workgroups along the input channels (see launch_wino4).  ksplit <= 1: an ordinary launch
+// over the given tile positions of every image.
+struct TailSplit {
+    int per_image;    // tiles of ONE image that belong to this launch: positions pos0 .. pos0 + per_image - 1 of its tiles_x * tiles_y tiles --
+    int pos0;         // the same positions of every image, so that an item's result does not depend on its slot in the batch
+    int ksplit;       // slices per tile (1: none)
+    int cps;          // 4-channel chunks per slice
+    float *ws;        // [ksplit][tiles of the launch][Cout][tile rows][tile columns]
+};
+
 // ---- the kernel: pair-split positions ------------------------------------------------------------------------------------------------
 // The first version gave every wave 16 couts x 16 tiles x all 36 positions (no exchange at all), so the FOUR waves that share a tile
 // group each made the same 36 B operands: 144 VALU operations per 36 MFMAs of 32 cycles, the largest single cost (20 % of its time;
@@ -183,8 +193,9 @@ __device__ __forceinline__ void bt3_row(const float (&d)[6], float (&t)[3]) {   
 
 template <int CB, int TG, int GW, int HJ>
 __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
-                                            float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                                            int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
+                                            float *__restrict__ y, int Cin_all, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
+                                            int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2,
+                                            const TailSplit ts) {
     using G = Geo4<CB, TG, GW>;
     constexpr int kRowP = G::kRowP, kRawW = G::kRawW;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 3 x [raw | U]
@@ -200,9 +211,15 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
     // One-dimensional grid of nblk tiles x ngroups cout groups.  Workgroups i, i+8, ... share an XCD: each XCD gets a contiguous run of
     // tiles (halo re-reads hit its L2) and runs the cout groups of one tile BACK TO BACK, so that the second group finds the input
     // tile in that L2 instead of fetching it again (PMC: 2.17x -> 1.4x the algorithmic bytes on dc_conv1).
-    int bid, grp;
+    // Tail launch (ts.ksplit > 1, see launch_wino4): the tiles of the last, partial round of workgroups, each cut into ksplit slices
+    // of the input channels; a slice leaves its raw partial outputs in the workspace, wino4_tail_reduce_kernel finishes them.
+    int bid, grp, kz = 0;
     {
-        const int id = (int)blockIdx.x;
+        int id = (int)blockIdx.x;
+        if (ts.ksplit > 1) {
+            kz = id / (nblk * ngroups);                   // slice-major: the slices of a tile land on the same XCD
+            id -= kz * (nblk * ngroups);
+        }
         if ((nblk & 7) == 0) {
             const int slot = id >> 3;
             grp = slot % ngroups;
@@ -212,10 +229,11 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
             bid = id % nblk;
         }
     }
-    const int tx = bid % tiles_x;
-    bid /= tiles_x;
-    const int ty = bid % tiles_y;
-    const int b = bid / tiles_y;
+    const int tail_tile = bid;                                  // index inside this launch (the workspace is laid out by it)
+    const int b = bid / ts.per_image;
+    const int pos = ts.pos0 + bid % ts.per_image;
+    const int tx = pos % tiles_x;
+    const int ty = pos / tiles_x;
     const int cb0 = co0 + grp * G::kCoutT;
     const int ox0 = tx * G::kGW;
     const int oy0 = ty * (G::kGH * TG);
@@ -240,10 +258,13 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
     const unsigned u_off = (unsigned)((tid / G::kCoutT) * CoutP + tid % G::kCoutT) * 16u;
     const unsigned u_step = (unsigned)(kThreads / G::kCoutT) * (unsigned)CoutP * 16u;
 
-    const float *xb = x + (int64_t)b * bsx;
-    const int nchunks = (Cin + kCK - 1) / kCK;
     const int64_t uchunk = (int64_t)36 * kCK * CoutP;                 // floats per chunk of the packed image
-    const float *ug = up + (int64_t)cb0 * 4;
+    // this workgroup's range of 4-channel chunks: everything, or slice kz of the tail launch
+    const int k_lo = kz * ts.cps, k_hi = ts.ksplit > 1 ? min((Cin_all + kCK - 1) / kCK, k_lo + ts.cps) : (Cin_all + kCK - 1) / kCK;
+    const int Cin = min(Cin_all, k_hi * kCK) - k_lo * kCK;
+    const int nchunks = k_hi - k_lo;
+    const float *xb = x + (int64_t)b * bsx + (int64_t)k_lo * kCK * plane;
+    const float *ug = up + (int64_t)cb0 * 4 + (int64_t)k_lo * uchunk;
     const int ubytes = (int)(uchunk - (int64_t)cb0 * 4) * 4;
     const unsigned lds0 = pwc::lds_addr(smem);
 
@@ -468,17 +489,22 @@ __device__ __forceinline__ void wino4p_body(const float *__restrict__ x, const f
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int co = cb0 + 32 * cg2 + 16 * HJ + 4 * (lane_e >> 4) + c;
-        const float bv = bias[min(co, Cout - 1)];
+        const float bv = ts.ksplit > 1 ? 0.f : bias[min(co, Cout - 1)];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             float o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 o[q] = keep[c][pp][q] + xrecv[((c * 4 + pp) * 4 + q) * 64] + bv;
-                if (do_leaky) o[q] = leaky(o[q], slope);
+                if (do_leaky && ts.ksplit <= 1) o[q] = leaky(o[q], slope);
             }
             const int oy = oyl + pp;
-            if (co < Cout && oy < H && ox < W) {
+            if (ts.ksplit > 1) {
+                // raw partial sums of slice kz: workspace [slice][tile of the tail][cout of the layer][tile rows][tile columns]
+                if (co < Cout)
+                    *reinterpret_cast<f32x4 *>(ts.ws + ((((int64_t)kz * nblk + tail_tile) * Cout + co) * (G::kGH * TG) + (oy - oy0)) * G::kGW + (ox - ox0)) =
+                        (f32x4){o[0], o[1], o[2], o[3]};
+            } else if (co < Cout && oy < H && ox < W) {
                 if (!split2) {
                     *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + (int64_t)co * plane + (int64_t)oy * W + ox) = (f32x4){o[0], o[1], o[2], o[3]};
                 } else {
@@ -495,12 +521,44 @@ template <int CB, int TG, int GW>
 __global__ void __launch_bounds__(kThreads, 1)
 conv3x3_wino4p_kernel(const float *__restrict__ x, const float *__restrict__ up, const float *__restrict__ bias,
                       float *__restrict__ y, int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                      int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2) {
+                      int64_t bsx, int64_t bsy, float slope, int do_leaky, int co0, int nblk, int ngroups, int split2, const TailSplit ts) {
     // the position half is wave-uniform: two specialisations of the body, every index inside is a compile-time constant
     if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 1)
-        wino4p_body<CB, TG, GW, 1>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
+        wino4p_body<CB, TG, GW, 1>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2, ts);
     else
-        wino4p_body<CB, TG, GW, 0>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2);
+        wino4p_body<CB, TG, GW, 0>(x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, nblk, ngroups, split2, ts);
+}
+
+// Finishes the tiles of a tail launch: y = act(bias + sum over slices, in slice order (deterministic)) for couts co0 .. co0 + ncout - 1
+// of the ntail tiles of the tail launch; one thread per four pixels of a tile row.
+__global__ void __launch_bounds__(256)
+wino4_tail_reduce_kernel(const float *__restrict__ ws, const float *__restrict__ bias, float *__restrict__ y, int ksplit, int per_image, int pos0,
+                         int ntail, int tiles_x, int th, int tw, int H, int W, int Cout, int co0, int ncout, int64_t bsy, float slope,
+                         int do_leaky, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int q4 = tw >> 2;
+    const int xq = (int)(idx % q4);
+    int64_t t = idx / q4;
+    const int r = (int)(t % th);
+    t /= th;
+    const int co = co0 + (int)(t % ncout);
+    const int tt = (int)(t / ncout);
+    const int b = tt / per_image, pos = pos0 + tt % per_image;
+    const int tx = pos % tiles_x, ty = pos / tiles_x;
+    const int oy = ty * th + r, ox = tx * tw + 4 * xq;
+    if (co >= Cout || oy >= H || ox >= W) return;
+    const int64_t slice = (int64_t)ntail * Cout * th * tw;
+    const float *p = ws + (((int64_t)tt * Cout + co) * th + r) * tw + 4 * xq;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+    for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4 *>(p + z * slice);
+    const float bv = bias[co];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] += bv;
+        if (do_leaky) v[i] = leaky(v[i], slope);
+    }
+    *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + ((int64_t)co * H + oy) * W + ox) = v;
 }
 
 // Inverse of L nested PWC_CONV_SPLIT2 stores (see pwc_hip.h): one thread per four output pixels of a row; the four come from four
@@ -529,21 +587,65 @@ lattice_unsplit_kernel(const float *__restrict__ x, float *__restrict__ y, int C
 
 inline int cout_padded4(int Cout) { return (Cout + 31) / 32 * 32; }
 
+// One workgroup per CU at a time, so a launch of n workgroups takes ceil(n / 256) rounds and its last round may leave most of the
+// chip idle: 896 workgroups (the 64-cout layers of level 2) = 3.5 rounds cost 4, 448 = 1.75 cost 2 -- 12.5 % of those layers.  When the
+// last round is partial (and at least one full round precedes it) its tiles go into a second launch that cuts every tile into
+// two slices of the input channels, so that the slices fill the chip (128 tiles x 2 = 256 half-length workgroups); a small third
+// kernel adds the slices in a fixed order.  PWC_W4_TAILSPLIT=0 switches it off.
+constexpr int kCUs = 256;
+struct TailPlan { int main_tiles, ksplit, cps; int64_t ws_bytes; };
+
+// The tail is made of the same (last) tile positions of EVERY image, so the result of an item does not depend on its slot in the batch.
+inline TailPlan wino4_tail_plan(int B, int64_t nblk, int ngroups, int nchunks, int Cout, int tile_px, int split2) {
+    TailPlan p{(int)nblk, 1, nchunks, 0};
+    static const int knob = [] { const char *e = getenv("PWC_W4_TAILSPLIT"); return (e && *e) ? atoi(e) : 1; }();
+    const int64_t nwg = nblk * ngroups, full = nwg / kCUs, rem = nwg - full * kCUs;
+    if (!knob || split2 || full < 1 || rem == 0 || (kCUs % ngroups) != 0) return p;
+    const int64_t main_tiles = full * kCUs / ngroups, tail = nblk - main_tiles;
+    if ((main_tiles & 7) || (tail & 7) || (tail % B)) return p;  // keep the XCD-aware tile order of both launches; whole positions
+    // Two slices, and only when they fit ONE half-length round (rem <= 128 workgroups): a slice costs ~10 us outside its K loop, so four
+    // quarter-length slices per tile measured no gain (448 workgroups = 1.75 rounds: 297 us unsplit, 314 us as 256 + 768 quarter slices),
+    // while 896 = 3 rounds + 256 half slices gains 7-10 % (conv2_3 728 -> 668 us, the 64-cout launch of conv2_2 580 -> 542 us).
+    const int best = (nchunks / 2 >= 12 && rem * 2 <= kCUs) ? 2 : 1;
+    if (best == 1) return p;
+    p.main_tiles = (int)main_tiles;
+    p.ksplit = best;
+    p.cps = (nchunks + best - 1) / best;
+    p.ws_bytes = (int64_t)best * tail * Cout * tile_px * (int64_t)sizeof(float);
+    return p;
+}
+
 template <int CB, int TG, int GW>
 int launch_wino4(const float *x, const float *up, const float *bias, float *y, int B, int Cin, int H, int W, int Cout,
-                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups, int split2) {
+                 int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st, int co0, int ngroups, int split2,
+                 void *workspace, int64_t workspace_bytes) {
     using G = Geo4<CB, TG, GW>;
     constexpr int kSmemP = G::kSmemBytes > 8 * 64 * 64 * 4 ? G::kSmemBytes : 8 * 64 * 64 * 4;       // rings, or the 128 KiB of the final exchange
     static pwc::LdsAttrOnce once;
     if (const int rc = pwc::ensure_lds_attr(once, reinterpret_cast<const void *>(&conv3x3_wino4p_kernel<CB, TG, GW>), kSmemP, "conv3x3_wino4p_kernel"))
         return rc;
     const int CoutP = cout_padded4(Cout);
-    const int tiles_x = (W + GW - 1) / GW, tiles_y = (H + G::kGH * TG - 1) / (G::kGH * TG);
+    constexpr int kTH = G::kGH * TG;
+    const int tiles_x = (W + GW - 1) / GW, tiles_y = (H + kTH - 1) / kTH;
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
     if (nblk * ngroups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
-    hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG, GW>), dim3((unsigned)(nblk * ngroups)), dim3(kThreads), kSmemP, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, (int)nblk, ngroups, split2);
-    pwc::note_kernel("conv3x3_wino4p_kernel", CB, TG, GW, 1, 1, 0);
+    TailPlan tp = wino4_tail_plan(B, nblk, ngroups, (Cin + kCK - 1) / kCK, Cout, kTH * GW, split2);
+    if (tp.ksplit > 1 && (!workspace || workspace_bytes < tp.ws_bytes || (reinterpret_cast<uintptr_t>(workspace) & 15u))) tp = TailPlan{(int)nblk, 1, 0, 0};
+    hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG, GW>), dim3((unsigned)(tp.main_tiles * ngroups)), dim3(kThreads), kSmemP, st,
+                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, tp.main_tiles, ngroups, split2,
+                       TailSplit{tp.main_tiles / B, 0, 1, 0, nullptr});
+    if (tp.ksplit > 1) {
+        const int ntail = (int)nblk - tp.main_tiles;
+        float *ws = static_cast<float *>(workspace);
+        hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG, GW>), dim3((unsigned)(ntail * ngroups * tp.ksplit)), dim3(kThreads), kSmemP, st,
+                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, ntail, ngroups, 0,
+                           TailSplit{ntail / B, tp.main_tiles / B, tp.ksplit, tp.cps, ws});
+        const int ncout = min(ngroups * G::kCoutT, Cout - co0);
+        const int64_t total = (int64_t)ntail * ncout * kTH * (GW / 4);
+        hipLaunchKernelGGL(wino4_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           ws, bias, y, tp.ksplit, ntail / B, tp.main_tiles / B, ntail, tiles_x, kTH, GW, H, W, Cout, co0, ncout, bsy, slope, do_leaky, total);
+    }
+    pwc::note_kernel("conv3x3_wino4p_kernel", CB, TG, GW, tp.ksplit, 1, 0);
     return pwc::check_launch("conv3x3_wino4p_kernel");
 }
 
@@ -601,7 +703,8 @@ extern "C" int pwc_conv3x3_wino4_pack(const void *w, void *up, int Cin, int Cout
 }
 
 extern "C" int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *bias, void *y, int B, int Cin, int H, int W, int Cout,
-                                     int dilation, unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride, void *stream) {
+                                     int dilation, unsigned flags, float leaky_slope, int64_t x_bstride, int64_t y_bstride,
+                                     void *workspace, int64_t workspace_bytes, void *stream) {
     if (!x || !up || !bias || !y) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: null pointer");
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: bad shape");
     if (!wino4_supported(W, dilation))
@@ -623,18 +726,30 @@ extern "C" int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *
     // 64-cout workgroups (4 cout blocks x 2 tile groups) for as many pairs of 32 as there are, one 32-cout launch (2 x 4) for an odd rest
     if (wino4_gw(W) == 64) {
         if (n32 >= 2)
-            if (const int rc = launch_wino4<4, 2, 64>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2))
+            if (const int rc = launch_wino4<4, 2, 64>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2, workspace, workspace_bytes))
                 return rc;
         if (n32 & 1)
-            return launch_wino4<2, 4, 64>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2);
+            return launch_wino4<2, 4, 64>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2, workspace, workspace_bytes);
     } else {
         if (n32 >= 2)
-            if (const int rc = launch_wino4<4, 2, 32>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2))
+            if (const int rc = launch_wino4<4, 2, 32>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, 0, n32 / 2, split2, workspace, workspace_bytes))
                 return rc;
         if (n32 & 1)
-            return launch_wino4<2, 4, 32>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2);
+            return launch_wino4<2, 4, 32>(xf, uf, bf, yf, B, Cin, H, W, Cout, x_bstride, y_bstride, leaky_slope, do_leaky, st, (n32 / 2) * 64, 1, split2, workspace, workspace_bytes);
     }
     return PWC_OK;
+}
+
+// Scratch for the tail split of launch_wino4 (0: this layer's launches have no partial last round worth splitting)
+extern "C" int64_t pwc_conv3x3_wino4_workspace_bytes(int B, int Cin, int H, int W, int Cout) {
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || !wino4_supported(W, 1)) return 0;
+    const int n32 = cout_padded4(Cout) / 32, nchunks = (Cin + kCK - 1) / kCK;
+    const int gw = wino4_gw(W), gh = gw == 64 ? 4 : 8;
+    const int64_t tiles_x = (W + gw - 1) / gw;
+    int64_t need = 0;
+    if (n32 >= 2) need = max(need, wino4_tail_plan(B, (int64_t)B * tiles_x * ((H + 2 * gh - 1) / (2 * gh)), n32 / 2, nchunks, Cout, 2 * gh * gw, 0).ws_bytes);
+    if (n32 & 1) need = max(need, wino4_tail_plan(B, (int64_t)B * tiles_x * ((H + 4 * gh - 1) / (4 * gh)), 1, nchunks, Cout, 4 * gh * gw, 0).ws_bytes);
+    return need;
 }
 
 extern "C" int pwc_lattice_unsplit_f32(const void *x, void *y, int B, int C, int h, int w, int levels, int64_t y_bstride, void *stream) {

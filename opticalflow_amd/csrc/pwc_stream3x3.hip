@@ -18,7 +18,7 @@
 //     and/or 64 (UPFEAT) v_pk_fma_f32 on (co0, co1) accumulator pairs: input broadcast x tap pair.  Plain
 //     v_fma_f32 runs at half that rate on gfx950 and these kernels are VALU-bound once the stream is hidden;
 //   * epilogue: bias, optional LeakyReLU / residual (HEAD), 16-byte stores.
-// Needs W % 4 == 0, W >= 128 and 16-byte aligned tensors; the dispatchers in pwc_conv.hip / pwc_deconv.hip
+// Needs W % 4 == 0, W >= 64 (PWC_STREAM_MINW) and 16-byte aligned tensors; the dispatchers in pwc_conv.hip / pwc_deconv.hip
 // use other kernels otherwise.
 #include "pwc_common.h"
 #include <cstdlib>
@@ -398,7 +398,8 @@ namespace pwc_conv {
 
 // true when the streaming kernel applies to this geometry (the callers keep their other kernels otherwise)
 bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx) {
-    return (W % 4 == 0) && (W >= 128) && al16(x) && (bsx % 4 == 0) && ((int64_t)H * W * kCK * 4 < 0x7fffffffLL) &&
+    static const int min_w = [] { const char *e = getenv("PWC_STREAM_MINW"); return (e && *e) ? atoi(e) : 64; }();    // 64-column maps (level 4) run half-filled 128-column tiles: still ahead of split-K MFMA head + deconv (-45 us)
+    return (W % 4 == 0) && (W >= min_w) && al16(x) && (bsx % 4 == 0) && ((int64_t)H * W * kCK * 4 < 0x7fffffffLL) &&
            (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8) >= 64;    // fewer: the split-K MFMA head + deconv kernel win (24 measured: -1.6 % at batch 4)
 }
 

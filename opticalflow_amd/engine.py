@@ -152,6 +152,7 @@ class PwcPlan:
         self.packed: Dict[str, torch.Tensor] = {}
         self.wino_packed: Dict[str, torch.Tensor] = {}
         self.wino4_packed: Dict[str, torch.Tensor] = {}        # F(4x4,3x3) banks, packed on first use by the layers the rule picks
+        self.split96_bias: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.conv_macs = {"direct": 0, "executed": 0}
         self.wino = os.environ.get("PWC_CONV_WINO", "1") != "0" and dtype == torch.float32
         self.wino4 = os.environ.get("PWC_CONV_WINO4", "1") != "0"          # 0: large layers stay on F(2x2,3x3) (A/B runs, error budget)
@@ -192,13 +193,13 @@ class PwcPlan:
                         w4 = self.p["dc_conv4.0.weight"]
                         self.dc4_split = bool(w4.shape[0] == 96 and ops.conv3x3_wino4_preferred(64 * B, w4.shape[1], h2 // 8, w2 // 8, 64))
                         if self.dc4_split:
-                            self.wino4_packed["dc_conv4.0[:64]"] = ops.pack_conv3x3_wino4(w4[:64].contiguous())
-                            self.wino_packed["dc_conv4.0[64:]"] = ops.pack_conv3x3_wino(w4[64:].contiguous())
-                            self.dc4_bias = (self.p["dc_conv4.0.bias"][:64].contiguous(), self.p["dc_conv4.0.bias"][64:].contiguous())
+                            self._pack_split96("dc_conv4.0")
                 for key, b_, cin, co, l in geo:
                     h, w = self.size[l]
                     if key in self.wino_packed and ops.conv3x3_wino4_preferred(b_, cin, h, w, co):
                         self.wino4_packed[key] = ops.pack_conv3x3_wino4(self.p[key + ".weight"])
+                    elif key in self.wino_packed and self._split96_wanted(b_, cin, h, w, co):
+                        self._pack_split96(key)
             # one split-K scratch shared by every stride-1 conv of the decoder (they run back to back on one stream)
             need = 0
             for l in range(2 if trunk2 else 3, 7):
@@ -208,6 +209,8 @@ class PwcPlan:
                     need = max(need, ops.conv3x3_workspace_bytes(B, cin, h, w, co))
                     if self.wino and co >= 32:
                         need = max(need, ops.conv3x3_wino_workspace_bytes(B, cin, h, w, co))
+                        if self.wino4:                                  # tail split of the F(4x4) launches (and of the 64-cout part of a 96-cout layer)
+                            need = max(need, ops.conv3x3_wino4_workspace_bytes(B, cin, h, w, co), ops.conv3x3_wino4_workspace_bytes(B, cin, h, w, min(co, 64)))
                     cin += co if co != 2 else 0
             # the context layers can split too (dilated: D*D lattices; at small batch / image sizes they fall into the split-K
             # window) -- pwc_conv3x3_wino_preferred counts the split, so the workspace must be there for it
@@ -230,11 +233,39 @@ class PwcPlan:
         """first / second image's level features as dense views of the pyramid buffer"""
         return buf[:B], buf[B:]
 
+    # ---- 96-cout layers as 64 couts on F(4x4) + 32 couts on F(2x2) -----------------------------------------------------
+    # A 32-cout F(4x4) launch is four tile groups per workgroup: on a map that gives the 64-cout launch (two groups) enough workgroups it
+    # leaves half the chip idle (conv3_2 at batch 16: 128 workgroups; dc_conv4 on its 14x32 lattice images), so the rule says no to the
+    # whole layer.  Its first 64 couts still fill F(4x4); the last 32 go to F(2x2), whose 32-cout workgroups are smaller.
+    @staticmethod
+    def _split96_wanted(b: int, cin: int, h: int, w: int, cout: int) -> bool:
+        return bool(cout == 96 and not ops.conv3x3_wino4_preferred(b, cin, h, w, 96) and ops.conv3x3_wino4_preferred(b, cin, h, w, 64)
+                    and ops.conv3x3_wino_preferred(b, cin, h, w, 32, 1))
+
+    def _pack_split96(self, key: str) -> None:
+        w, b = self.p[key + ".weight"], self.p[key + ".bias"]
+        self.wino4_packed[key + "[:64]"] = ops.pack_conv3x3_wino4(w[:64].contiguous())
+        self.wino_packed[key + "[64:]"] = ops.pack_conv3x3_wino(w[64:].contiguous())
+        self.split96_bias[key] = (b[:64].contiguous(), b[64:].contiguous())
+
+    def _conv_split96(self, key: str, x: torch.Tensor, out: torch.Tensor, act: bool = True) -> None:
+        macs = x.shape[0] * 96 * x.shape[1] * 9 * x.shape[2] * x.shape[3]
+        self.conv_macs["direct"] += macs
+        self.conv_macs["executed"] += macs * 2 // 3 * 36 // 144 + macs // 3 * 16 // 36
+        b0, b1 = self.split96_bias[key]
+        slope = LEAKY if act else None
+        ops.conv3x3_wino4(x, self.wino4_packed[key + "[:64]"], b0, 64, leaky_slope=slope, out=out[:, :64], workspace=self.workspace)
+        ops.conv3x3_wino(x, self.wino_packed[key + "[64:]"], b1, 32, leaky_slope=slope, out=out[:, 64:], workspace=self.workspace)
+
     # ---- layer primitives -----------------------------------------------------------------------
     def _conv(self, name: str, x: torch.Tensor, out: torch.Tensor, stride: int = 1, dilation: int = 1,
               act: bool = True, residual: Optional[torch.Tensor] = None) -> None:
         key = name + ".0" if (name + ".0.weight") in self.p else name
         w, b = self.p[key + ".weight"], self.p[key + ".bias"]
+        if (key + "[:64]") in self.wino4_packed and stride == 1 and dilation == 1 and residual is None and self._split96_wanted(
+                x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0]):
+            self._conv_split96(key, x, out, act)
+            return
         macs = x.shape[0] * w.shape[0] * w.shape[1] * 9 * ((x.shape[2] - 1) // stride + 1) * ((x.shape[3] - 1) // stride + 1)
         self.conv_macs["direct"] += macs                          # what the layer costs as a direct convolution
         if (self.wino and self.wino4 and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and dilation == 1 and residual is None
@@ -242,7 +273,7 @@ class PwcPlan:
             # Winograd F(4x4,3x3): 4x fewer multiplications than the direct form for the large, well-filled layers (gated: DESIGN.md 4b)
             if key not in self.wino4_packed:
                 self.wino4_packed[key] = ops.pack_conv3x3_wino4(w)      # first (eager, warm-up) run; a captured replay finds it packed
-            ops.conv3x3_wino4(x, self.wino4_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out)
+            ops.conv3x3_wino4(x, self.wino4_packed[key], b, w.shape[0], leaky_slope=LEAKY if act else None, out=out, workspace=self.workspace)
             self.conv_macs["executed"] += macs * 36 // 144
             return
         if (self.wino and key in self.wino_packed and self.conv_backend == "hip" and stride == 1 and residual is None and x.dtype == torch.float32
@@ -397,13 +428,7 @@ class PwcPlan:
         w4("dc_conv2", self.ctx[0], self.ctx[1], True)            # dilation 2 = 1 on those -> 16B x [128,H/4,W/4]
         w4("dc_conv3", self.ctx[1], self.ctx[2], True)            # dilation 4 = 1          -> 64B x [128,H/8,W/8]
         if getattr(self, "dc4_split", False):                     # dilation 8 = 1 on the dilation-8 lattices: 64 couts F(4x4) + 32 couts F(2x2)
-            x4 = self.ctx[2]
-            macs = x4.shape[0] * 96 * x4.shape[1] * 9 * x4.shape[2] * x4.shape[3]
-            self.conv_macs["direct"] += macs
-            self.conv_macs["executed"] += macs * 2 // 3 * 36 // 144 + macs // 3 * 16 // 36
-            ops.conv3x3_wino4(x4, self.wino4_packed["dc_conv4.0[:64]"], self.dc4_bias[0], 64, leaky_slope=LEAKY, out=self.ctx[3][:, :64])
-            ops.conv3x3_wino(x4, self.wino_packed["dc_conv4.0[64:]"], self.dc4_bias[1], 32, leaky_slope=LEAKY, out=self.ctx[3][:, 64:],
-                             workspace=self.workspace)
+            self._conv_split96("dc_conv4.0", self.ctx[2], self.ctx[3])
         else:
             self._conv("dc_conv4", self.ctx[2], self.ctx[3], dilation=1)
         self._conv("dc_conv5", self.ctx[3], self.ctx4_lat, dilation=2)      # dilation 16 = 2 on them

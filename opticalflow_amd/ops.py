@@ -9,6 +9,7 @@ does no validation and silently assumes contiguous NCHW
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -352,11 +353,29 @@ def pack_conv3x3_wino4(weight: torch.Tensor) -> torch.Tensor:
     return up
 
 
+def _workspace_args(workspace: Optional[torch.Tensor], x: torch.Tensor) -> Tuple[int, int]:
+    if workspace is None:
+        return 0, 0
+    if workspace.device != x.device or not workspace.is_contiguous():
+        raise ValueError("workspace must be a contiguous tensor on %s" % x.device)
+    return workspace.data_ptr(), workspace.numel() * workspace.element_size()
+
+
+def conv3x3_wino4_workspace_bytes(B: int, cin: int, H: int, W: int, cout: int) -> int:
+    """Scratch bytes the tail split of this layer's F(4x4) launches wants (0 = no partial last round worth splitting)."""
+    n = _lib.load().pwc_conv3x3_wino4_workspace_bytes(B, cin, H, W, cout)
+    if n < 0:
+        raise ValueError("bad conv geometry")
+    return int(n)
+
+
 def conv3x3_wino4(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, cout: int, leaky_slope: Optional[float] = 0.1,
-                  out: Optional[torch.Tensor] = None, split2: bool = False) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, split2: bool = False, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3 / stride 1 / padding 1 convolution + bias (+ LeakyReLU) by Winograd F(4x4,3x3) on the matrix cores (fp32; W % 4 == 0).
     split2: the result is stored as its four pixel lattices, [4B, cout, H/2, W/2] with image 4b + 2(y & 1) + (x & 1) -- the input
-    layout in which the next, twice-as-dilated layer is a dilation-1 convolution (lattice_unsplit is the inverse)."""
+    layout in which the next, twice-as-dilated layer is a dilation-1 convolution (lattice_unsplit is the inverse).
+    workspace (conv3x3_wino4_workspace_bytes): lets a launch whose last round of workgroups would leave most CUs idle run that
+    round's tiles as input-channel slices (same result up to the fp32 summation order of those tiles; deterministic)."""
     lib = _lib.load()
     bsx = _plane_dense(x, "x")
     B, cin, H, W = x.shape
@@ -375,10 +394,11 @@ def conv3x3_wino4(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, co
         raise ValueError("packed F(4x4,3x3) filters do not match Cin=%d Cout=%d (have %d B, need %d B)" % (cin, cout, upacked.numel() * 4, need))
     if bias.dtype != torch.float32 or bias.numel() != cout or bias.device != x.device or not bias.is_contiguous():
         raise ValueError("bias must be float32[%d] on %s" % (cout, x.device))
+    ws_ptr, ws_bytes = _workspace_args(workspace, x)
     with torch.cuda.device(x.device):
         rc = lib.pwc_conv3x3_wino4_fwd(x.data_ptr(), upacked.data_ptr(), bias.data_ptr(), out.data_ptr(), B, cin, H, W, cout, 1,
                                        (FLAG_ACT_LEAKY if leaky_slope is not None else 0) | (_lib.FLAG_CONV_SPLIT2 if split2 else 0),
-                                       float(leaky_slope or 0.0), bsx, bsy, _stream(x))
+                                       float(leaky_slope or 0.0), bsx, bsy, ws_ptr, ws_bytes, _stream(x))
     check(rc, "pwc_conv3x3_wino4_fwd")
     return out
 
@@ -410,7 +430,7 @@ def conv3x3_workspace_bytes(B: int, cin: int, H: int, W: int, cout: int, stride:
 
 def head_upfeat_supported(B: int, H: int, W: int) -> bool:
     """Geometry gate of pwc_head_upfeat_fwd (mirrors stream3x3_ok in csrc/pwc_stream3x3.hip)."""
-    return W % 4 == 0 and W >= 128 and B * ((W + 127) // 128) * ((H + 7) // 8) >= 64
+    return W % 4 == 0 and W >= int(os.environ.get("PWC_STREAM_MINW", "64")) and B * ((W + 127) // 128) * ((H + 7) // 8) >= 64
 
 
 def head_upfeat(x: torch.Tensor, head_wpacked: torch.Tensor, head_bias: torch.Tensor, up_weight: torch.Tensor,

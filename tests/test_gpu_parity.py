@@ -998,6 +998,53 @@ def test_conv3x3_winograd4_baseline_shapes_vs_fp64(gpu_device):
 
 
 @pytest.mark.gpu
+def test_conv3x3_winograd4_tail_split_vs_fp64(gpu_device):
+    """With a workspace, an F(4x4) launch whose last round of workgroups is partial runs that round's tiles as input-channel slices
+    (csrc/pwc_conv_wino4.hip launch_wino4): conv2_3 (469 -> 64 @16x112x256: 896 workgroups = 3.5 rounds, the last 128 tiles as two
+    slices -- the last two tile rows of every image) and conv2_2 (373 -> 96: its 64-cout launch) exactly as the plan launches them;
+    conv2_4 (448 workgroups = 1.75 rounds) does not split.  Items 0 and 15 against fp64 under the F(4x4) budget; the unsplit tile rows are
+    bit-identical to a launch without workspace, the split ones differ only by the summation order; bit-repeatable; independent of
+    the batch slot."""
+    from opticalflow_amd import ops, _lib
+    B, H, W = 16, 112, 256
+    assert ops.conv3x3_wino4_workspace_bytes(B, 533, H, W, 32) == 0
+    for name, cin, cout in (("conv2_3", 469, 64), ("conv2_2", 373, 96)):
+        need = max(ops.conv3x3_wino4_workspace_bytes(B, cin, H, W, cout), ops.conv3x3_wino4_workspace_bytes(B, cin, H, W, min(cout, 64)))
+        assert need > 0, name
+        ws = torch.empty(need // 4, device=gpu_device)
+        gen = torch.Generator(device=gpu_device).manual_seed(3000 + cin)
+        arena = torch.randn(B, 565, H, W, generator=gen, device=gpu_device)
+        g = torch.Generator().manual_seed(cin * 5 + cout)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        x = arena[:, 565 - cin:]
+        out = arena[:, 565 - cin - cout:565 - cin]                     # the slice in front of its input, as in the dense block
+        up, bd = ops.pack_conv3x3_wino4(w.to(gpu_device)), b.to(gpu_device)
+        ops.conv3x3_wino4(x, up, bd, cout, out=out, workspace=ws)
+        kern = _lib.load().pwc_last_conv_kernel().decode()
+        assert "wino4p" in kern, kern
+        got = out.clone()
+        ops.conv3x3_wino4(x, up, bd, cout, out=out, workspace=ws)
+        assert torch.equal(out, got)                                     # fixed slice order: repeatable
+        plain = ops.conv3x3_wino4(x, up, bd, cout)
+        # the tail is the same tile positions of EVERY image (here the last two 8-row tile rows): rows above are bit-identical to the
+        # unsplit launch, rows below differ by the summation order of the Winograd-domain products
+        assert torch.equal(plain[:, :, :96], got[:, :, :96])
+        d = (plain - got).abs().amax(dim=(1, 2, 3))
+        assert d.min().item() > 0 and d.max().item() <= 8.1e-5
+        # ... so an item's result does not depend on its slot in the batch
+        same = x[:1].expand(B, -1, -1, -1).contiguous()
+        r = ops.conv3x3_wino4(same, up, bd, cout, workspace=ws)
+        assert all(torch.equal(r[0], r[i]) for i in range(1, B))
+        torch.set_num_threads(max(8, torch.get_num_threads()))
+        for i in (0, B - 1):
+            ref = F.leaky_relu(F.conv2d(x[i:i + 1].cpu().double(), w.double(), b.double(), padding=1), 0.1)
+            err = (got[i:i + 1].cpu().double() - ref).abs().max().item()
+            print("%s item %d: %s max err %.2e (budget %.2e), split vs unsplit %.2e" % (name, i, kern, err, 1e-6 * (cin * 9) ** 0.5, d[i].item()))
+            assert err <= 1e-6 * (cin * 9) ** 0.5
+
+
+@pytest.mark.gpu
 def test_forward_winograd4_error_budget(gpu_device, monkeypatch):
     """Whole-forward gate of the F(4x4) route on the benchmark workload, 16 x 6 x 448 x 1024 -- where the rule sends
     twelve level-2 / level-3 / pyramid / context layers to F(4x4): EPE of items 0 and 15 against the CPU oracle below 1e-4, the whole

@@ -74,11 +74,16 @@ def test_abi_argument_errors_without_gpu():
     assert p4(1024, 128, 14, 32, 64, 1) == 1         # narrow maps: 2 x 8 tile groups
     assert p4(16, 16, 224, 512, 16, 1) == 0 and p4(16, 64, 112, 254, 64, 1) == 0
     vp = ctypes.c_void_p
-    assert lib.pwc_conv3x3_wino4_fwd(None, vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 1, 0, 0.0, 32 * 512, 32 * 512, None) == -1
-    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 62, 32, 1, 0, 0.0, 32 * 496, 32 * 496, None) == -2   # W % 4
-    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 2, 0, 0.0, 32 * 512, 32 * 512, None) == -2   # dilation
-    assert lib.pwc_conv3x3_wino4_fwd(vp(4100), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 1, 0, 0.0, 32 * 512, 32 * 512, None) == -3   # alignment
-    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 7, 64, 32, 1, 32, 0.0, 32 * 448, 32 * 448, None) == -1  # SPLIT2: odd H
+    assert lib.pwc_conv3x3_wino4_fwd(None, vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 1, 0, 0.0, 32 * 512, 32 * 512, None, 0, None) == -1
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 62, 32, 1, 0, 0.0, 32 * 496, 32 * 496, None, 0, None) == -2   # W % 4
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 2, 0, 0.0, 32 * 512, 32 * 512, None, 0, None) == -2   # dilation
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4100), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 1, 0, 0.0, 32 * 512, 32 * 512, None, 0, None) == -3   # alignment
+    # tail split of the F(4x4) launches: 896 workgroups (64 couts at level 2, batch 16) = 3.5 rounds on 256 CUs -> the last 128 tiles as two
+    # input-channel slices; 1792 workgroups (128 couts) = 7 whole rounds -> nothing to split; short K (8 chunks) -> no split
+    wsb = lib.pwc_conv3x3_wino4_workspace_bytes
+    assert wsb(16, 469, 112, 256, 64) == 2 * 128 * 64 * 8 * 64 * 4
+    assert wsb(16, 565, 112, 256, 128) == 0 and wsb(32, 32, 112, 256, 32) == 0 and wsb(0, 32, 8, 64, 32) == 0
+    assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 7, 64, 32, 1, 32, 0.0, 32 * 448, 32 * 448, None, 0, None) == -1  # SPLIT2: odd H
     assert lib.pwc_lattice_unsplit_f32(vp(4096), vp(4096), 1, 8, 4, 5, 1, 8 * 8 * 10, None) == -3                                               # W % 4 after unsplit
     assert lib.pwc_lattice_unsplit_f32(vp(4096), vp(4096), 1, 8, 4, 6, 0, 8 * 8 * 12, None) == -1
     # split filters: 16 couts per 32-row tile -> twice the rows beyond Cout = 16, the plain size up to there (ABI v8)
