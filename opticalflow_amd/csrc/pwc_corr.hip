@@ -226,6 +226,9 @@ corr81_kernel(const T *__restrict__ in1, const T *__restrict__ in2, T *__restric
 //   * zero padding, ragged edges and the ragged last channel chunk come from the buffer range check.
 // Needs W % 4 == 0 and 16-byte aligned operands (the launcher falls back to corr81_kernel otherwise).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef PWC_CORR_EXP
+#define PWC_CORR_EXP 0       // timing experiments on corr81_dma_kernel (results invalid): 1 = the fma waves skip the arithmetic, 2 = every fetch reads
+#endif                       // channel chunk 0 of tile 0 (cache-resident), 4 = no LDS-DMA inside the loop, 8 = no output stores
 constexpr int kCKd = 4;                                   // channels per chunk
 #ifndef PWC_CORR_RING
 #define PWC_CORR_RING 3
@@ -343,13 +346,14 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
         const float *ip1 = nullptr, *ip2 = nullptr;
         auto issue_next = [&]() {
             if (is_step >= nsteps) return;
-            if (is_chunk == 0) {
+            if (is_chunk == 0 && (!(PWC_CORR_EXP & 2) || is_step == 0)) {
                 const TileXY t = tile_of(is_tile, nblk, tiles_x, tiles_y);
                 corr_offsets(off, lane, t, H, W, plane);
                 ip1 = in1 + (int64_t)t.b * bs1;
                 ip2 = in2 + (int64_t)t.b * bs2;
             }
-            corr_issue<WARP>(ip1, ip2, is_chunk * kCKd, C, plane, smem + (is_step % kRing) * kBufFloats, off);
+            if (!(PWC_CORR_EXP & 4) || is_step < kRing - 1)
+                corr_issue<WARP>(ip1, ip2, (PWC_CORR_EXP & 2) ? 0 : is_chunk * kCKd, C, plane, smem + (is_step % kRing) * kBufFloats, off);
             ++is_step;
             if (++is_chunk == nchunks) { is_chunk = 0; is_tile += stride; }
         };
@@ -473,7 +477,7 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
         const float *s2 = cur + (r + wave) * kPitch + 4 * g;
         const float *s1 = cur + kS2Floats + r * kPitch + 4 * g;
 #pragma unroll 2
-        for (int c = 0; c < kCKd; ++c) {
+        for (int c = 0; c < ((PWC_CORR_EXP & 1) ? 0 : kCKd); ++c) {
             const float4 a4 = *reinterpret_cast<const float4 *>(s1 + c * kTH * kPitch);
             const float4 w0 = *reinterpret_cast<const float4 *>(s2 + c * kS2Rows * kPitch);
             const float4 w1 = *reinterpret_cast<const float4 *>(s2 + c * kS2Rows * kPitch + 4);
@@ -496,7 +500,7 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
             const TileXY t = tile_of(tile, nblk, tiles_x, tiles_y);
             const int y = t.y0 + r;
             const int x = t.x0 + 4 * g;
-            if (y < H && x < W) {
+            if (y < H && x < W && !(PWC_CORR_EXP & 8)) {
                 float *po = out + (int64_t)t.b * bso + (int64_t)(wave * kND) * plane + (int64_t)y * W + x;
 #pragma unroll
                 for (int dx = 0; dx < kND; ++dx) {
