@@ -193,6 +193,19 @@ int64_t pwc_conv3x3_wino4_workspace_bytes(int B, int Cin, int H, int W, int Cout
  * (dense planes, free batch stride); image index ((b*4 + s1)*4 + s2)... with s_i = 2 (y_i & 1) + (x_i & 1), coarsest split first. */
 int pwc_lattice_unsplit_f32(const void *x, void *y, int B, int C, int h, int w, int levels, int64_t y_bstride, void *stream);
 
+/* ---- image-space pre / post of the KITTI evaluation loop (reference inference_kitti.py:53-91,175-178,208-224; csrc/pwc_kitti.hip) ----
+ * pwc_kitti_ingest_u8: uint8 RGB pairs [n][2][H][W][3] -> x float [n][6][Hp][Wp] (Hp, Wp = H, W rounded up to multiples of 64; free batch
+ *   stride in elements, multiple of 4; 16-byte aligned): ToTensor (/ 255), (v - mean3[c]) / std3[c] (host pointers, read at the call),
+ *   the two images concatenated along the channels, replicate padding at the bottom / right -- what the reference does with
+ *   torchvision transforms, torch.cat and F.pad(mode="replicate") before the model.
+ * pwc_flow_upsample_f32: the model's quarter-resolution flow [n][2][Hq][Wq] (free batch stride) -> out [n][2][out_h][out_w] (dense):
+ *   crop to the top-left crop_h x crop_w, bilinear resize with align_corners = True (F.interpolate's arithmetic), u * (out_w / crop_w),
+ *   v * (out_h / crop_h) -- `unpad` + `flow_resize` of the reference.  Neither allocates nor synchronises. */
+int pwc_kitti_ingest_u8(const void *pairs_u8, void *x, int n, int H, int W, const float *mean3, const float *std3,
+                        int64_t x_bstride, void *stream);
+int pwc_flow_upsample_f32(const void *flow_q, void *out, int n, int Hq, int Wq, int crop_h, int crop_w, int out_h, int out_w,
+                          int64_t q_bstride, void *stream);
+
 /* ---- fp16 convolution (first piece of the half-precision path, BASELINE configs 3-4) --------------------------
  * Activations are channel-blocked "c8": [B][ceil(C/8)][H][W][8] halves, channels past C zero; only the batch
  * stride (in halves, multiple of 8) is free, so a tensor may be a channel-group slice of an arena.  fp32

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pwc_conv3x3_wino4_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_float,
                                      c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "pwc_conv3x3_wino4_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "pwc_kitti_ingest_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "pwc_flow_upsample_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "pwc_lattice_unsplit_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "pwc_conv2d_f16_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_uint, c_float, c_int64, c_int64, c_void_p]),

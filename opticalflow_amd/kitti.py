@@ -16,6 +16,7 @@ stream while the previous pair is being processed (double buffering); normalisat
 """
 from __future__ import annotations
 
+import os
 import struct
 import zlib
 from typing import Iterable, Iterator, Optional, Tuple
@@ -23,6 +24,8 @@ from typing import Iterable, Iterator, Optional, Tuple
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+from . import ops
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
@@ -88,6 +91,11 @@ def model_infer(model, img1: torch.Tensor, img2: torch.Tensor, reference_unpad: 
     x, ph, pw = pad_to_64(torch.cat([img1, img2], dim=1))
     out = model(x)
     flow = out[0] if isinstance(out, (tuple, list)) else out          # finest level first in the training tuple
+    if flow.is_cuda and flow.dtype == torch.float32:
+        # unpad + bilinear resize + rescale as one kernel (the same one the captured pipeline uses; tests hold it to flow_resize)
+        hq, wq = flow.shape[-2:]
+        ch, cw = (hq - ph, wq - pw) if reference_unpad else (hq - ph // 4, wq - pw // 4)
+        return ops.flow_upsample(flow, ch, cw, h, w)
     flow = unpad(flow, ph, pw) if reference_unpad else unpad(flow, ph // 4, pw // 4)
     return flow_resize(flow, h, w)
 
@@ -300,6 +308,8 @@ class GraphedInfer:
     def __init__(self, model, height: int, width: int, device: torch.device, reference_unpad: bool = True, batch: int = 1):
         self.model, self.reference_unpad, self.batch = model, reference_unpad, batch
         self.static_u8 = torch.zeros((batch, 2, height, width, 3), dtype=torch.uint8, device=device)
+        self.x_in = torch.empty((batch, 6, (height + 63) // 64 * 64, (width + 63) // 64 * 64), dtype=torch.float32, device=device)
+        self.flow_full = torch.empty((batch, 2, height, width), dtype=torch.float32, device=device)
         keep, model.use_graph = getattr(model, "use_graph", False), False      # no nested capture
         try:
             side = torch.cuda.Stream(device=device)
@@ -314,14 +324,25 @@ class GraphedInfer:
             model.use_graph = keep
 
     def _body(self) -> torch.Tensor:
-        i1, i2 = normalize_pair(self.static_u8[:, 0], self.static_u8[:, 1])
-        h, w = i1.shape[-2:]
-        x, ph, pw = pad_to_64(torch.cat([i1, i2], dim=1))
+        h, w = self.static_u8.shape[2:4]
+        ph, pw = (64 - h % 64) % 64, (64 - w % 64) % 64
+        if os.environ.get("PWC_KITTI_TORCH_PREPOST") == "1":
+            # the same steps as ~30 PyTorch launches (what round 2 captured; kept for A/B runs and as the statement the kernels are tested against)
+            i1, i2 = normalize_pair(self.static_u8[:, 0], self.static_u8[:, 1])
+            x, ph, pw = pad_to_64(torch.cat([i1, i2], dim=1))
+            out = self.model(x)
+            self.flow_quarter = out[0] if isinstance(out, (tuple, list)) else out
+            flow = unpad(self.flow_quarter, ph, pw) if self.reference_unpad else unpad(self.flow_quarter, ph // 4, pw // 4)
+            return flow_resize(flow, h, w)
+        # ToTensor + normalisation + cat + replicate pad as ONE kernel, unpad + bilinear resize + rescale as another (csrc/pwc_kitti.hip):
+        # as PyTorch launches they were 14.6 % of the fp16 stream's GPU time
+        x = ops.kitti_ingest(self.static_u8, IMAGENET_MEAN, IMAGENET_STD, out=self.x_in)
         out = self.model(x)
         # the network's own output [batch,2,H_/4,W_/4] (a static buffer like `out`): what a sharded stream gathers
         self.flow_quarter = out[0] if isinstance(out, (tuple, list)) else out
-        flow = unpad(self.flow_quarter, ph, pw) if self.reference_unpad else unpad(self.flow_quarter, ph // 4, pw // 4)
-        return flow_resize(flow, h, w)
+        hq, wq = self.flow_quarter.shape[-2:]
+        ch, cw = (hq - ph, wq - pw) if self.reference_unpad else (hq - ph // 4, wq - pw // 4)
+        return ops.flow_upsample(self.flow_quarter, ch, cw, h, w, out=self.flow_full)
 
     def __call__(self, pair_u8: torch.Tensor) -> torch.Tensor:
         """pair_u8: [2,H,W,3] (one pair) or [n,2,H,W,3] with n <= batch; returns the first n flows [n,2,H,W]."""

@@ -403,6 +403,46 @@ def conv3x3_wino4(x: torch.Tensor, upacked: torch.Tensor, bias: torch.Tensor, co
     return out
 
 
+def kitti_ingest(pairs_u8: torch.Tensor, mean, std, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 RGB pairs [n,2,H,W,3] on the device -> float32 [n,6,Hp,Wp] (Hp, Wp = H, W rounded up to multiples of 64): ToTensor +
+    (v - mean) / std per channel, the two images concatenated along the channels, replicate padding (inference_kitti.py:53-63,175-178,
+    208-210) as one kernel (C-ABI pwc_kitti_ingest_u8)."""
+    import ctypes
+    if not pairs_u8.is_cuda or pairs_u8.dtype != torch.uint8 or pairs_u8.dim() != 5 or pairs_u8.shape[1] != 2 or pairs_u8.shape[4] != 3 \
+            or not pairs_u8.is_contiguous():
+        raise ValueError("pairs_u8 must be a contiguous uint8 device tensor [n,2,H,W,3]")
+    n, _, H, W, _ = pairs_u8.shape
+    Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
+    if out is None:
+        out = torch.empty((n, 6, Hp, Wp), dtype=torch.float32, device=pairs_u8.device)
+    elif tuple(out.shape) != (n, 6, Hp, Wp) or out.dtype != torch.float32 or out.device != pairs_u8.device:
+        raise ValueError("out must be float32 %s" % ((n, 6, Hp, Wp),))
+    bso = _plane_dense(out, "out")
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    with torch.cuda.device(pairs_u8.device):
+        rc = _lib.load().pwc_kitti_ingest_u8(pairs_u8.data_ptr(), out.data_ptr(), n, H, W, m3, s3, bso, _stream(pairs_u8))
+    check(rc, "pwc_kitti_ingest_u8")
+    return out
+
+
+def flow_upsample(flow_q: torch.Tensor, crop_h: int, crop_w: int, out_h: int, out_w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[n,2,Hq,Wq] -> [n,2,out_h,out_w]: crop to the top-left crop_h x crop_w, bilinear resize (align_corners=True), u * out_w / crop_w,
+    v * out_h / crop_h -- `unpad` + `flow_resize` of inference_kitti.py:66-91 as one kernel (C-ABI pwc_flow_upsample_f32)."""
+    if not flow_q.is_cuda or flow_q.dtype != torch.float32 or flow_q.dim() != 4 or flow_q.shape[1] != 2:
+        raise ValueError("flow_q must be a float32 device tensor [n,2,Hq,Wq]")
+    n, _, Hq, Wq = flow_q.shape
+    bsq = _plane_dense(flow_q, "flow_q")
+    if out is None:
+        out = torch.empty((n, 2, out_h, out_w), dtype=torch.float32, device=flow_q.device)
+    elif tuple(out.shape) != (n, 2, out_h, out_w) or out.dtype != torch.float32 or out.device != flow_q.device or not out.is_contiguous():
+        raise ValueError("out must be contiguous float32 %s" % ((n, 2, out_h, out_w),))
+    with torch.cuda.device(flow_q.device):
+        rc = _lib.load().pwc_flow_upsample_f32(flow_q.data_ptr(), out.data_ptr(), n, Hq, Wq, crop_h, crop_w, out_h, out_w, bsq, _stream(flow_q))
+    check(rc, "pwc_flow_upsample_f32")
+    return out
+
+
 def lattice_unsplit(x: torch.Tensor, batch: int, levels: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Inverse of `levels` nested split2 stores: [batch * 4**levels, C, h, w] (contiguous) -> [batch, C, h << levels, w << levels]."""
     if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4 or x.shape[0] != batch * 4 ** levels:

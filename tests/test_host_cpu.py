@@ -78,6 +78,16 @@ def test_abi_argument_errors_without_gpu():
     assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 62, 32, 1, 0, 0.0, 32 * 496, 32 * 496, None, 0, None) == -2   # W % 4
     assert lib.pwc_conv3x3_wino4_fwd(vp(4096), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 2, 0, 0.0, 32 * 512, 32 * 512, None, 0, None) == -2   # dilation
     assert lib.pwc_conv3x3_wino4_fwd(vp(4100), vp(4096), vp(4096), vp(4096), 1, 32, 8, 64, 32, 1, 0, 0.0, 32 * 512, 32 * 512, None, 0, None) == -3   # alignment
+    # KITTI pre / post kernels (csrc/pwc_kitti.hip): argument checks come before any launch
+    m3 = (ctypes.c_float * 3)(0.485, 0.456, 0.406)
+    s3 = (ctypes.c_float * 3)(0.229, 0.224, 0.225)
+    z3 = (ctypes.c_float * 3)(0.229, 0.0, 0.225)
+    assert lib.pwc_kitti_ingest_u8(None, vp(4096), 1, 8, 8, m3, s3, 6 * 64 * 64, None) == -1
+    assert lib.pwc_kitti_ingest_u8(vp(4096), vp(4100), 1, 8, 8, m3, s3, 6 * 64 * 64, None) == -3          # alignment
+    assert lib.pwc_kitti_ingest_u8(vp(4096), vp(4096), 1, 8, 8, m3, s3, 6 * 64 * 64 - 4, None) == -3      # batch stride < 6*Hp*Wp
+    assert lib.pwc_kitti_ingest_u8(vp(4096), vp(4096), 1, 8, 8, m3, z3, 6 * 64 * 64, None) == -1          # zero std
+    assert lib.pwc_flow_upsample_f32(vp(4096), vp(4096), 1, 16, 16, 17, 16, 64, 64, 2 * 256, None) == -1   # crop larger than the map
+    assert lib.pwc_flow_upsample_f32(vp(4096), None, 1, 16, 16, 16, 16, 64, 64, 2 * 256, None) == -1
     # tail split of the F(4x4) launches: 896 workgroups (64 couts at level 2, batch 16) = 3.5 rounds on 256 CUs -> the last 128 tiles as two
     # input-channel slices; 1792 workgroups (128 couts) = 7 whole rounds -> nothing to split; short K (8 chunks) -> no split
     wsb = lib.pwc_conv3x3_wino4_workspace_bytes

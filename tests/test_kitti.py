@@ -131,6 +131,37 @@ def test_model_infer_and_stream_on_gpu(gpu_device):
 
 
 @pytest.mark.gpu
+def test_ingest_and_upsample_kernels_vs_torch_statement(gpu_device):
+    """csrc/pwc_kitti.hip against the torch expressions of the host mirror (= inference_kitti.py:53-91,175-178,208-224): ToTensor +
+    ImageNet normalisation + cat + replicate pad is bit-identical to normalize_pair / torch.cat / pad_to_64 on the device; unpad +
+    F.interpolate(align_corners=True) + rescale agrees with flow_resize to rounding (the interpolation's multiply-adds may contract
+    differently), on the KITTI geometry (375x1242 -> 384x1280, the reference's quarter-resolution crop 87x282) and ragged small ones."""
+    from opticalflow_amd import kitti, ops
+    g = torch.Generator().manual_seed(21)
+    for n, h, w in ((2, 375, 1242), (3, 100, 150), (1, 64, 128), (1, 65, 67)):
+        u8 = torch.randint(0, 256, (n, 2, h, w, 3), generator=g, dtype=torch.uint8).to(gpu_device)
+        i1, i2 = kitti.normalize_pair(u8[:, 0], u8[:, 1])
+        ref, ph, pw = kitti.pad_to_64(torch.cat([i1, i2], dim=1))
+        got = ops.kitti_ingest(u8, kitti.IMAGENET_MEAN, kitti.IMAGENET_STD)
+        assert got.shape == ref.shape and torch.equal(got, ref)
+        # into a batch-strided view, as a plan's input buffer may be
+        big = torch.zeros((n, 8) + tuple(ref.shape[2:]), device=gpu_device)
+        ops.kitti_ingest(u8, kitti.IMAGENET_MEAN, kitti.IMAGENET_STD, out=big[:, :6])
+        assert torch.equal(big[:, :6], ref) and float(big[:, 6:].abs().max()) == 0.0
+        hq, wq = ref.shape[2] // 4, ref.shape[3] // 4
+        q = (torch.randn(n, 2, hq, wq, generator=g) * 3).to(gpu_device)
+        for crop in ((hq - ph, wq - pw), (hq - ph // 4, wq - pw // 4)):
+            if min(crop) <= 0:
+                continue
+            want = kitti.flow_resize(q[..., :crop[0], :crop[1]], h, w)
+            have = ops.flow_upsample(q, crop[0], crop[1], h, w)
+            assert have.shape == want.shape
+            assert (have - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.kitti_ingest(torch.zeros((1, 2, 8, 8, 3), dtype=torch.float32, device=gpu_device), kitti.IMAGENET_MEAN, kitti.IMAGENET_STD)
+
+
+@pytest.mark.gpu
 def test_graphed_infer_equals_eager_pipeline(gpu_device):
     """kitti.GraphedInfer (normalise + pad + forward + unpad + resize as one HIP graph) returns exactly what the eager
     model_infer does, pair after pair, fed by PairStream(raw=True)."""

@@ -49,6 +49,12 @@ PWC_BENCH_SPLIT=1 python3 "$ROOT/tools/bench_conv_f16.py" > "$OUT/f16_microbench
 python3 "$ROOT/tools/bench_corr.py" > "$OUT/microbench_corr.txt" 2>&1
 python3 "$ROOT/tools/bench_bwd.py" > "$OUT/microbench_bwd.txt" 2>&1
 
+say "KITTI stream: share of the GPU time in kernels that are not ours (PyTorch pre/post launches inside the captured graph)"
+for p in fp16 fp32; do
+  rocprofv3 --kernel-trace --stats -d "$OUT/ks" -o p --output-format csv -- python3 "$ROOT/bench.py" --workload kitti --precision $p --steps 20 --warmup 5 > /dev/null 2>&1
+  python3 "$ROOT/tools/kernel_share.py" "$(find "$OUT/ks" -name "*kernel_stats.csv" | head -1)" > "$OUT/kitti_share_$p.txt"; rm -rf "$OUT/ks"
+done
+
 say "PMC passes (one counter per run): calibration, dc_conv1 F(4x4) / fp16, fused warp+corr, plain corr"
 : > "$OUT/pmc_summary.txt"
 for c in FETCH_SIZE WRITE_SIZE; do

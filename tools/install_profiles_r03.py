@@ -21,6 +21,7 @@ COPIES = {
     "rehearse_n2_fp32.json": "r03_rehearse_n2_fp32.json", "rehearse_n2_kitti.json": "r03_rehearse_n2_kitti.json",
     "forward_timeline_b16.txt": "r03_forward_timeline_b16.txt", "f16_forward_timeline_b16.txt": "r03_f16_forward_timeline_b16.txt",
     "f16s_forward_timeline_b16.txt": "r03_f16strict_forward_timeline_b16.txt",
+    "kitti_share_fp16.txt": "r03_kitti_share_fp16.txt", "kitti_share_fp32.txt": "r03_kitti_share_fp32.txt",
     "kernel_stats_bench_b16.csv": "r03_kernel_stats_bench_b16.csv", "f16_kernel_stats_bench_b16.csv": "r03_f16_kernel_stats_bench_b16.csv",
     "kernel_stats_wino4_dc_conv1.csv": "r03_kernel_stats_wino4_dc_conv1_alone.csv", "f16_kernel_stats_dc_conv1.csv": "r03_f16_kernel_stats_dc_conv1_alone.csv",
     "kernel_stats_warpcorr.csv": "r03_kernel_stats_warpcorr_alone.csv", "pmc_summary.txt": "r03_pmc_summary.txt",
