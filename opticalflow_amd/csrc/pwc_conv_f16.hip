@@ -56,6 +56,27 @@ struct G16 {
     static constexpr bool kValid = kSmem <= 160 * 1024 && (!kRowSep || S == 1);
 };
 
+// One-dimensional grid of nblk tiles x ngroups cout groups (ngroups = cout tiles of the layer / MT, recomputed from CoutP).
+// Workgroups i, i+8, i+16, ... run on the same XCD: each XCD gets a contiguous run of tiles (the halo rows / columns re-read by
+// neighbouring tiles hit in its L2) and -- round 3 -- runs the cout groups of one tile BACK TO BACK, so that the second (third, fourth:
+// split filters) group finds the input tile in that L2 instead of fetching it from HBM again: the 8-wave kernel's two 64-cout
+// groups cost 1.90x the algorithmic traffic with the groups in blockIdx.y (all tiles of group 0, then all of group 1).
+// Speed only; any mapping is correct.  -DPWC_F16_NO_XCD_MAP: plain order.
+__device__ __forceinline__ void block_to_tile(int ngroups, int &bid, int &g) {
+    const int nblk = (int)gridDim.x / ngroups;
+    const int id = (int)blockIdx.x;
+#ifndef PWC_F16_NO_XCD_MAP
+    if ((nblk & 7) == 0) {
+        const int slot = id >> 3;
+        g = slot % ngroups;
+        bid = (id & 7) * (nblk >> 3) + slot / ngroups;
+        return;
+    }
+#endif
+    g = id / nblk;
+    bid = id % nblk;
+}
+
 // loader wave: start the LDS-DMA of one 16-channel chunk (input halo tile, then the filter slab) into its ring slot
 template <class G>
 __device__ __forceinline__ void issue_f16(const _Float16 *xb, const _Float16 *wp, int chunk, int Cg, int plane, int CoutP,
@@ -82,17 +103,12 @@ conv3x3_f16_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    int bid = blockIdx.x;
-#ifndef PWC_F16_NO_XCD_MAP
-    // workgroups i, i+8, i+16, ... run on the same XCD: deal the tiles so that each XCD owns a contiguous run of them and
-    // the halo rows / columns re-read by neighbouring tiles hit in that XCD's L2 (speed only; any mapping is correct)
-    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
-#endif
+    int bid, g;
+    block_to_tile((CoutP / 32 + MT - 1) / MT, bid, g);
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int g = blockIdx.y;
     const int ox0 = tx * kTileW;
     const int oy0 = ty * G::kTileH;
     const int plane = H * W;
@@ -253,15 +269,12 @@ conv3x3_f16w8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict_
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    int bid = blockIdx.x;
-#ifndef PWC_F16_NO_XCD_MAP
-    if ((gridDim.x & 7u) == 0) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
-#endif
+    int bid, g;
+    block_to_tile((CoutP / 32 + MT - 1) / MT, bid, g);
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int g = blockIdx.y;
     const int ox0 = tx * kTileW;
     const int oy0 = ty * G::kTileH;
     const int plane = H * W;
@@ -486,7 +499,7 @@ int launch16(const Args16 &a) {
         const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
         const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
         const int groups = (a.CoutP / 32 + MT - 1) / MT;
-        if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
+        if (nblk * groups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
         auto kern = conv3x3_f16_kernel<MT, NT, S, D, R>;
         static pwc::LdsAttrOnce attr;
         if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
@@ -494,7 +507,7 @@ int launch16(const Args16 &a) {
         // smaller LDS footprint lets several workgroups share a CU and cover each other's single DMA round trip
         const int nchunks = (a.Cg + 1) / 2;
         const int smem = (nchunks < R ? nchunks : R) * G::kSlotBytes;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kBlock), smem, a.stream,
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * groups)), dim3(kBlock), smem, a.stream,
                            a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo, tiles_x, tiles_y,
                            a.bsx, a.bsy, a.slope, a.mode);
         pwc::note_kernel("conv3x3_f16_kernel", MT, NT, S, D, R, 0);
@@ -516,11 +529,11 @@ int launch16w8s(const Args16 &a) {
     const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
     const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
     const int groups = (a.CoutP / 32 + MT - 1) / MT;
-    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
+    if (nblk * groups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_f16_fwd: grid too large");
     auto kern = conv3x3_f16w8_kernel<MT, D, SH>;
     static pwc::LdsAttrOnce attr;
     if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmem, "pwc_conv2d_f16_fwd")) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(512), G::kSmem, a.stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * groups)), dim3(512), G::kSmem, a.stream,
                        a.x, a.wp, a.bias, a.y, a.Cg, a.H, a.W, a.Cout, a.CoutP, tiles_x, tiles_y,
                        a.bsx, a.bsy, a.slope, a.mode);
     pwc::note_kernel("conv3x3_f16w8_kernel", MT, 2, 1, D, 2, SH ? 16 : 32);
