@@ -16,6 +16,8 @@ int run_s2d1(const ConvArgs &a);
 int run_head(const float *x, const float *w_raw, const float *bias, const float *residual, float *y,
              int B, int Cin, int H, int W, int Cout, int64_t bsx, int64_t bsy, int64_t bsr,
              float slope, int do_leaky, hipStream_t st);
+int image_conv_s2(const float *x, const float *wp, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int CoutP,
+                  int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st);      // pwc_conv_image.hip
 bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx);
 int stream3x3_head(const float *x, const float *w, const float *bias, const float *residual, float *y,
                    int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, int64_t bsr,
@@ -147,6 +149,11 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
     a.slope = leaky_slope;
     a.do_leaky = (flags & PWC_ACT_LEAKY) ? 1 : 0;
     a.stream = static_cast<hipStream_t>(stream);
+    if (Cin == 3 && Cout == 16 && stride == 2 && dilation == 1 && !a.residual) {
+        // conv1a on the image: its own kernel (16-byte patch loads, filters in registers) where the geometry allows it
+        const int rc = pwc_conv::image_conv_s2(a.x, a.wp, a.bias, a.y, B, Cin, H, W, Cout, a.CoutP, a.bsx, a.bsy, a.slope, a.do_leaky, a.stream);
+        if (rc != PWC_EUNSUPPORTED) return rc;
+    }
     // split-K: few output tiles and a long Cin -> partial sums over Cin ranges into the caller's workspace, then
     // a fixed-order reduction.  Without a (large enough) workspace the layer runs unsplit.
     const pwc_conv::SplitPlan sp = split_for(B, Cin, H, W, Cout, stride, dilation);

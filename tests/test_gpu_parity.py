@@ -455,6 +455,30 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.gpu
+def test_conv1a_image_kernel_vs_fp64(gpu_device):
+    """conv1a (3 -> 16, stride 2, PWCNet.py:52,184) has its own kernel (csrc/pwc_conv_image.hip): full tiles (448x1024), ragged
+    tiles (100x152 -> 50x76), the two images as channel slices of one [B,6,H,W] tensor exactly as the plan passes them, no activation,
+    and a width the kernel does not take (W % 4 != 0 -> the generic kernel) -- all against fp64 conv2d."""
+    from opticalflow_amd import ops, _lib
+    g = torch.Generator().manual_seed(77)
+    w = torch.randn(16, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    b = torch.randn(16, generator=g) * 0.1
+    wp, bd = ops.pack_conv3x3(w.to(gpu_device)), b.to(gpu_device)
+    for B, H, W, slope in ((2, 448, 1024, 0.1), (3, 100, 152, 0.1), (1, 64, 128, None), (2, 20, 46, 0.1)):
+        x6 = torch.rand(B, 6, H, W, generator=g)
+        xd = x6.to(gpu_device)
+        for lo in (0, 3):
+            got = ops.conv3x3(xd[:, lo:lo + 3], wp, bd, 16, stride=2, leaky_slope=slope).cpu()
+            kern = _lib.load().pwc_last_conv_kernel().decode()
+            assert ("image_conv_s2_f32" in kern) == (W % 4 == 0), (kern, W)
+            ref = F.conv2d(x6[:, lo:lo + 3].double(), w.double(), b.double(), stride=2, padding=1)
+            if slope is not None:
+                ref = F.leaky_relu(ref, slope)
+            assert got.shape == ref.shape
+            assert (got.double() - ref).abs().max().item() <= 3e-6 * 27 ** 0.5, (B, H, W, lo)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3x3_vs_torch_cpu(dev, case):
     from opticalflow_amd import ops

@@ -4,7 +4,7 @@
 usage: tools/timeline.py <kernel_trace.csv> [--full] [--min-grid=N] [--fp32 [--strict]]
 --fp32: the trace also holds fp16 forwards (bench.py's fp16_same_workload leg); pick the fp32 plan's forward.
 --strict (with --fp32): the fp16-strict plan, whose forward starts on the fp32 kernels and continues on the half-precision ones.
-A forward starts at the two back-to-back stride-2 launches of conv1a on the two images.
+A forward starts at the two back-to-back launches of conv1a on the two images.
 """
 import csv
 import re
@@ -36,7 +36,7 @@ def short(n):
         return "stream3x3<mode%s,TH%s,KS%s>" % m.groups()
     if "corr81_dma_kernel<true>" in n or "corr81_dma_kernelILb1E" in n:
         return "warp+corr81"
-    for k in ("pyr1_fused", "corr81_bwd", "corr81_c8", "warp_c8", "nchw_to_c8_hilo", "nchw_to_c8", "c8_to_nchw", "image_conv_s2"):
+    for k in ("pyr1_fused", "corr81_bwd", "corr81_c8", "warp_c8", "nchw_to_c8_hilo", "nchw_to_c8", "c8_to_nchw", "image_conv_s2_f32", "image_conv_s2"):
         if k in n:
             return k
     for k in ("stream3x3_kernel<1>", "stream3x3_kernel<2>", "stream3x3_kernel<3>", "conv3x3_head", "deconv4x4s2", "corr81", "corr_generic", "splitk_reduce", "warp_kernel", "copyBuffer", "elementwise", "pack3x3", "lattice_unsplit"):
@@ -61,7 +61,7 @@ def main():
     else:
         rows_ok = False
     starts = starts if rows_ok else [i for i in range(len(rows) - 1)
-              if names[i].startswith("mfma<") and ("S2,D1" in names[i]) and names[i + 1] == names[i]
+              if ((names[i].startswith("mfma<") and ("S2,D1" in names[i])) or names[i] == "image_conv_s2_f32") and names[i + 1] == names[i]
               and rows[i]["Grid_Size_X"] == rows[i + 1]["Grid_Size_X"] and int(rows[i]["Grid_Size_X"]) > min_grid]
     if len(starts) < 3:
         print("no forward found")
