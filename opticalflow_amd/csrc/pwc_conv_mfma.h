@@ -61,13 +61,20 @@ struct Geom {
     static constexpr int kWPS = TWO ? 2 : 1;                        // waves per SIMD the register budget must allow
     static constexpr int kTileH = 4 * NT;
     static constexpr bool kRowSep = (D >= 16);                      // stage the three ky row-sets separately
-    static constexpr int kInW = (kTileW - 1) * S + 2 * D + 1;
+    // A staged row starts kPadL >= D columns left of the tile, at a multiple of four input columns, and is a whole number of 16-byte
+    // pieces long: with W % 4 == 0 and 16-byte aligned tensors the tile then arrives as 16-byte LDS-DMA pieces (round 3: a third of the
+    // instructions of the dword form -- each costs the issuing wave 60-180 cycles -- which remains for other widths / alignments).
+    static constexpr int kPadL = (D + 3) / 4 * 4;
+    static constexpr int kInW = (kPadL + (kTileW - 1) * S + 1 + D + 3) / 4 * 4;    // row pitch (floats)
+    static constexpr int kCol0 = kPadL - D;                                        // staged index of the tile's first window column
     static constexpr int kInH = kRowSep ? 3 * kTileH : (kTileH - 1) * S + 2 * D + 1;
     static constexpr int kCH = kInH * kInW;                          // floats per staged channel (flat)
     static constexpr int kKyStride = kRowSep ? kTileH * kInW : D * kInW;
     static constexpr int kInElems = kCK * kCH;
     static constexpr int kInSlots = (kInElems + kThreads - 1) / kThreads;       // dword DMAs per thread per chunk
-    static constexpr int kInRegion = kInSlots * kThreads;                         // floats
+    static constexpr int kInSlots16 = (kInElems / 4 + kThreads - 1) / kThreads;   // 16-byte DMAs per thread per chunk
+    // floats: whole instructions of either form (the last 16-byte instruction of a chunk writes up to 1 KiB x 4 waves past kInElems)
+    static constexpr int kInRegion = kInSlots * kThreads > kInSlots16 * kThreads * 4 ? kInSlots * kThreads : kInSlots16 * kThreads * 4;
     static constexpr int kCoutT = 32 * MT;
     static constexpr int kWPieces = kCK * 9 * kCoutT / 4;                         // 16-byte pieces per chunk
     static constexpr int kWSlots = (kWPieces + kThreads - 1) / kThreads;
@@ -85,17 +92,24 @@ namespace {   // kernels and launchers have internal linkage: each translation u
 template <class G>
 __device__ __forceinline__ void issue_chunk(const float *xb, const float *wg, int chunk, int Cin, int plane,
                                             int64_t wchunk, unsigned wbytes, int wave, float *buf,
-                                            const unsigned *in_off, const unsigned *w_off) {
+                                            const unsigned *in_off, const unsigned *w_off, bool p16) {
     const int c0 = chunk * G::kCK;
     const int cvalid = min(G::kCK, Cin - c0);
     // descriptors built from readfirstlane'd words so hipcc can prove them wave-uniform
     // (otherwise every DMA is wrapped in a waterfall loop)
     __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(xb + (int64_t)c0 * plane), 0, __builtin_amdgcn_readfirstlane(cvalid * plane * 4), kRsrcFlags);
-    float *dst_in = buf + wave * 64;
+    if (p16) {                                  // wave-uniform: 16-byte pieces, piece j * 256 + tid lands at float 4 * (j * 256 + tid)
+        float *dst_in = buf + wave * 256;
 #pragma unroll
-    for (int j = 0; j < G::kInSlots; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(dst_in + j * kThreads), 4, in_off[j], 0, 0, 0);
+        for (int j = 0; j < G::kInSlots16; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(dst_in + j * kThreads * 4), 16, in_off[j], 0, 0, 0);
+    } else {
+        float *dst_in = buf + wave * 64;
+#pragma unroll
+        for (int j = 0; j < G::kInSlots; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void *)(dst_in + j * kThreads), 4, in_off[j], 0, 0, 0);
+    }
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         uniform_ptr(wg + (int64_t)chunk * wchunk), 0, __builtin_amdgcn_readfirstlane((int)wbytes), kRsrcFlags);
     float *dst_w = buf + G::kInRegion + wave * 256;
@@ -113,8 +127,9 @@ __global__ void __launch_bounds__(kThreads, (TWO ? 2 : 1))
 conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                     const float *__restrict__ residual, float *__restrict__ y,
                     int Cin, int H, int W, int Cout, int CoutP, int Ho, int Wo, int tiles_x, int tiles_y,
-                    int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky, int cps, int64_t zstride) {
+                    int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky, int cps, int64_t zstride, int p16i) {
     using G = Geom<MT, NT, S, D, TWO>;
+    const bool p16 = __builtin_amdgcn_readfirstlane(p16i) != 0;
     constexpr int CK = G::kCK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -142,7 +157,8 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     unsigned in_off[G::kInSlots];
 #pragma unroll
     for (int j = 0; j < G::kInSlots; ++j) {
-        const int i = j * kThreads + tid;
+        // element (dword form) or first element of the piece (16-byte form) number j * 256 + tid of the staged chunk [c][row][kInW]
+        const int i = p16 ? 4 * (j * kThreads + tid) : j * kThreads + tid;
         const int c = i / G::kCH;
         const int rem = i % G::kCH;
         const int r = rem / G::kInW;
@@ -153,7 +169,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
         } else {
             iy = oy0 * S - D + r;
         }
-        const int ix = ox0 * S - D + xx;
+        const int ix = ox0 * S - G::kPadL + xx;                 // 16-byte form: ix and W are multiples of 4 -> a piece is all-in or all-out
         const bool ok = (i < G::kInElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
         in_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
     }
@@ -190,7 +206,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
         chunk_lo = (int)blockIdx.z * cps;                       // host guarantees chunk_lo < nchunks
         chunk_hi = min(nchunks, chunk_lo + cps);
     }
-    issue_chunk<G>(xb, wg, chunk_lo, Cin, plane, wchunk, wbytes, wave, smem + (chunk_lo & 1) * G::kBufFloats, in_off, w_off);
+    issue_chunk<G>(xb, wg, chunk_lo, Cin, plane, wchunk, wbytes, wave, smem + (chunk_lo & 1) * G::kBufFloats, in_off, w_off, p16);
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         float *cur = smem + (chunk & 1) * G::kBufFloats;
         // This wave's DMA of `chunk` has landed (explicit wait: hipcc does not reliably keep its own
@@ -200,9 +216,9 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
         __syncthreads();
         if (chunk + 1 < chunk_hi)
             issue_chunk<G>(xb, wg, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
-                           in_off, w_off);
+                           in_off, w_off, p16);
 
-        const float *rd_in = cur + kh * G::kCH + (wave * NT) * S * G::kInW + col * S;
+        const float *rd_in = cur + kh * G::kCH + (wave * NT) * S * G::kInW + col * S + G::kCol0;
         const float *rd_w = cur + G::kInRegion + kh * 9 * G::kCoutT + col;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -266,8 +282,9 @@ __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                       const float *__restrict__ residual, float *__restrict__ y,
                       int Cin, int H, int W, int Cout, int CoutP, int tiles_x, int tiles_y,
-                      int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky) {
+                      int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky, int p16i) {
     using G = Geom<1, NT, 1, 1, 1, CKT>;
+    const bool p16 = __builtin_amdgcn_readfirstlane(p16i) != 0;
     constexpr int CK = G::kCK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -293,11 +310,11 @@ conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp,
     unsigned in_off[G::kInSlots];
 #pragma unroll
     for (int j = 0; j < G::kInSlots; ++j) {
-        const int i = j * kThreads + tid;
+        const int i = p16 ? 4 * (j * kThreads + tid) : j * kThreads + tid;      // see conv3x3_mfma_kernel
         const int c = i / G::kCH;
         const int rem = i % G::kCH;
         const int iy = oy0 - 1 + rem / G::kInW;
-        const int ix = ox0 - 1 + rem % G::kInW;
+        const int ix = ox0 - G::kPadL + rem % G::kInW;
         const bool ok = (i < G::kInElems) && (iy >= 0) && (iy < H) && (ix >= 0) && (ix < W);
         in_off[j] = ok ? (unsigned)(c * plane + iy * W + ix) * 4u : kOOB;
     }
@@ -323,15 +340,15 @@ conv3x3_mfma16_kernel(const float *__restrict__ x, const float *__restrict__ wp,
     const int64_t wchunk = (int64_t)CK * 9 * CoutP;
     const unsigned wbytes = (unsigned)wchunk * 4u;
 
-    issue_chunk<G>(xb, wp, 0, Cin, plane, wchunk, wbytes, wave, smem, in_off, w_off);
+    issue_chunk<G>(xb, wp, 0, Cin, plane, wchunk, wbytes, wave, smem, in_off, w_off, p16);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         float *cur = smem + (chunk & 1) * G::kBufFloats;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // see conv3x3_mfma_kernel
         __syncthreads();
         if (chunk + 1 < nchunks)
             issue_chunk<G>(xb, wp, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
-                           in_off, w_off);
-        const float *rd_in = cur + kg * G::kCH + (wave * NT) * G::kInW + acol;
+                           in_off, w_off, p16);
+        const float *rd_in = cur + kg * G::kCH + (wave * NT) * G::kInW + acol + G::kCol0;
         const float *rd_w = cur + G::kInRegion + kg * 9 * G::kCoutT + acol;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -386,6 +403,12 @@ struct ConvArgs {
     // `partial` [ksplit][B][Cout][Ho][Wo], `cps` chunks of 8 input channels per split
     float *partial = nullptr;
     int ksplit = 1, cps = 0;
+    // the input tile as 16-byte LDS-DMA pieces (W % 4 == 0, 16-byte aligned x, batch stride a multiple of 4); else dwords.
+    // PWC_CONV_P16=0 forces the dword form (A/B runs)
+    int p16() const {
+        static const bool on = [] { const char *e = getenv("PWC_CONV_P16"); return !(e && e[0] == '0'); }();
+        return on && (W % 4 == 0) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (bsx % 4 == 0);
+    }
 };
 
 // Split-K plan shared by pwc_conv2d_fwd and pwc_conv2d_workspace_bytes: ksplit (1 = do not split) and the
@@ -426,7 +449,7 @@ int launch(const ConvArgs &a) {
             return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
                            a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
-                           tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky, 0, (int64_t)0);
+                           tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky, 0, (int64_t)0, a.p16());
         pwc::note_kernel("conv3x3_mfma_kernel", MT, NT, S, D, TWO, 0);
         return pwc::check_launch("conv3x3_mfma_kernel");
     }
@@ -447,7 +470,7 @@ int launch_split(const ConvArgs &a) {
     const int64_t bsp = (int64_t)a.Cout * a.Ho * a.Wo;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups, (unsigned)a.ksplit), dim3(kThreads), G::kSmemBytes,
                        a.stream, a.x, a.wp, a.bias, (const float *)nullptr, a.partial, a.Cin, a.H, a.W, a.Cout, a.CoutP,
-                       a.Ho, a.Wo, tiles_x, tiles_y, a.bsx, bsp, (int64_t)0, 0.f, 0, a.cps, (int64_t)a.B * bsp);
+                       a.Ho, a.Wo, tiles_x, tiles_y, a.bsx, bsp, (int64_t)0, 0.f, 0, a.cps, (int64_t)a.B * bsp, a.p16());
     return pwc::check_launch("conv3x3_mfma_kernel<split>");
 }
 
@@ -468,7 +491,7 @@ int launch16(const ConvArgs &a) {
         return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(kThreads), G::kSmemBytes, a.stream,
                        a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, tiles_x, tiles_y,
-                       a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky);
+                       a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky, a.p16());
     return pwc::check_launch("conv3x3_mfma16_kernel");
 }
 
