@@ -234,6 +234,11 @@ def probes_fp16(result, plan, B, H, W, h2, w2, stream):
                           "avg_launch_ms": round(ms, 4), "launches_timed": PROBE_REPS, "algorithmic_flop_per_launch": flops}
     if "rocprof_avg_ms" in rec:
         result["roofline"]["frac_rocprof"] = round(flops / (rec["rocprof_avg_ms"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+        # the conv stack is power-limited: the same launch takes 0.49 ms on the plan's own (post-LeakyReLU) activations -- what `frac`
+        # times -- and 0.54-0.59 ms on the unit-scale gaussian operands of tools/bench_conv_f16.py -- what the rocprofv3 average times
+        result["roofline"]["frac_rocprof_operands"] = ("unit-scale gaussian (tools/bench_conv_f16.py); `frac` is timed on the plan's own "
+                                                       "activations: power-limited kernel, clock depends on the operand statistics "
+                                                       "(profiles/r03_f16_data_effect.txt)")
     ar = plan.arena[2]
     f0 = BASE_G + CORR_G
     c2 = 32
