@@ -2,7 +2,7 @@
 """Robustness sweep of the public forward over geometries the tests do not pin: random (batch, H, W) with H, W multiples of 64, fp32 /
 fp16-strict / fp16 against the CPU oracle on two items of every batch, plus batch-slot invariance (the same pair in every slot gives
 bit-identical flows).  Exercises whatever routes the rules pick at those sizes (F(4x4) with tail split, 64 + 32 cout split, F(2x2) split-K,
-streaming heads on narrow maps, lattice-major context network, 16-byte / dword staging).  usage: tools/fuzz_forward.py [seed] [cases]"""
+streaming heads on narrow maps, lattice-major context network, 16-byte / dword staging).  usage: python tests/fuzz_forward.py [seed] [cases]   (lives under tests/: it uses the CPU oracle as its checker)"""
 import os
 import sys
 
