@@ -15,9 +15,10 @@ flops are:
     the MFMA passes, fp32 accumulation), fp32 flow head and fp32 ``flow2 = predict_flow2 + dc_conv7`` as in the fast plan.  What
     remains is the rounding of the activations those layers store (conv2_*, dc_conv*);
   * the level-2 BASE channels [corr 81 | c1 32 | up_flow 2 | up_feat 2] -- computed in fp32, read by all seven level-2 consumers
-    -- are handed over as hi + lo halves: the rounding residual of each channel is stored as a second channel set
-    (pwc_nchw_to_c8_f16_hilo) whose filters are copies of the first set's, so those 117 inputs carry ~22 bits (+128 input
-    channels per consumer, +31 % of the level-2 block's MFMA passes).
+    -- are handed over with the rounding residual of corr and of the four flow channels stored as second channel sets
+    (pwc_nchw_to_c8_f16_hilo) whose filters are copies of the first sets', so those 85 inputs carry ~22 bits (+96 input channels
+    per consumer).  c1's residual is not carried: its rounding contributes 0.02e-4 of the EPE against 0.9e-4 (corr) and 1.2e-4
+    (up_flow / up_feat) in the what-if emulation.
 
 CPU emulation (tests/f16_error_budget.py): policy ``fffffss`` (pyr/dec6..3 fp32, dec2/ctx split) gives 0.35e-3 / 0.60e-3 /
 0.85e-3 / 0.85e-3 on the 64x64, 128x192, 448x1024 and KITTI-sized random inputs (fast plan: 0.61 / 1.09 / 1.59 / 1.81); measured
@@ -51,9 +52,14 @@ class PwcPlanStrict:
         self.size2 = (h2, w2)
         g2 = _groups(PYRAMID_CH[2])
         self.f0 = BASE_G + CORR_G                                   # first group of c1 inside the c8 arena
-        self.nbase = CORR_G + g2 + 1                                # groups of [corr | c1 | flow]; the residual set follows it
+        self.nbase = CORR_G + g2 + 1                                # groups of [corr | c1 | flow]
+        # the residual (lo) set follows: [corr residual | flow residual].  c1 gets none: the what-if emulation (tests/f16_error_budget.py
+        # kitti whatif, profiles/r03_f16_strict_budget.txt) attributes 0.9e-4 of the EPE to the rounding of corr, 1.2e-4 to the four
+        # up_flow / up_feat channels and 0.02e-4 to the 32 channels of c1
+        self.r_corr = BASE_G + self.nbase                           # first residual group of corr
+        self.r_flow = self.r_corr + CORR_G                          # residual group of [up_flow | up_feat]
         hk = dict(device=device, dtype=torch.float16)
-        self.arena = torch.zeros((B, BASE_G + 2 * self.nbase, h2, w2, 8), **hk)
+        self.arena = torch.zeros((B, self.r_flow + 1, h2, w2, 8), **hk)
         self.ctx = [torch.zeros((B, _groups(c), h2, w2, 8), **hk) for c, _ in CONTEXT]
         self.head = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
         self.dc7 = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
@@ -65,14 +71,16 @@ class PwcPlanStrict:
         self.cout: Dict[str, int] = {}
         p = prepare_params(params, variant, self.nd)
         nphys = int(self.arena.shape[1]) * 8
-        hi0, nb = BASE_G * 8, self.nbase * 8
+        corr0, flow0 = BASE_G * 8, (self.f0 + g2) * 8                 # physical channels of corr (88 with its pad) and of the flow group
+        rc0, rf0 = self.r_corr * 8, self.r_flow * 8
         for name, w, bias, _ in list(level_filters(p, 2, nphys, self.nd)) + list(context_filters(p)):
             if not name.startswith("dc_conv") or name == "dc_conv1":
                 # consumers of the level-2 arena: column j of w is physical channel (nphys - w.shape[1]) + j; the residual channel
-                # set gets the filters of the set it corrects
+                # sets get the filters of the sets they correct
                 ps = nphys - w.shape[1]
                 w = w.clone()
-                w[:, hi0 + nb - ps:hi0 + 2 * nb - ps] = w[:, hi0 - ps:hi0 + nb - ps]
+                w[:, rc0 - ps:rc0 + CORR_G * 8 - ps] = w[:, corr0 - ps:corr0 + CORR_G * 8 - ps]
+                w[:, rf0 - ps:rf0 + 8 - ps] = w[:, flow0 - ps:flow0 + 8 - ps]
             self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float(), split=True)       # EVERY layer: hi + lo filters
             self.b[name] = bias.contiguous().float()
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
@@ -99,10 +107,9 @@ class PwcPlanStrict:
         c = PYRAMID_CH[2]
         g2 = _groups(c)
         ar = self.arena
-        nb = self.nbase
-        F16.to_c8_hilo(base[:, 0:81], ar[:, BASE_G:BASE_G + CORR_G], ar[:, BASE_G + nb:BASE_G + nb + CORR_G])
-        F16.to_c8_hilo(base[:, 81:81 + c], ar[:, self.f0:self.f0 + g2], ar[:, self.f0 + nb:self.f0 + nb + g2])
-        F16.to_c8_hilo(base[:, 81 + c:81 + c + 4], ar[:, self.f0 + g2:self.f0 + g2 + 1], ar[:, self.f0 + nb + g2:self.f0 + nb + g2 + 1])
+        F16.to_c8_hilo(base[:, 0:81], ar[:, BASE_G:BASE_G + CORR_G], ar[:, self.r_corr:self.r_corr + CORR_G])
+        F16.to_c8(base[:, 81:81 + c], out=ar[:, self.f0:self.f0 + g2])
+        F16.to_c8_hilo(base[:, 81 + c:81 + c + 4], ar[:, self.f0 + g2:self.f0 + g2 + 1], ar[:, self.r_flow:self.r_flow + 1])
         # level-2 dense block, flow head, context network: half activations, split filters, fp32 accumulation
         lo = BASE_G
         for i, og in enumerate(DENSE_G):

@@ -139,13 +139,19 @@ def forward_policy(sd, x, pol, all_levels=False):
         hq = q if half else (lambda t: t)
         if lvl == 2 and pol.get("base2_exact"):          # what-if: the level-2 base channels (corr, c1, up_flow, up_feat) stored hi + lo
             hq = lambda t: t
-        c1, c2 = hq(feats[0][lvl - 1]), hq(feats[1][lvl - 1])
+        # what-if: only SOME of the level-2 base channels stored hi + lo ("corr", "c1", "flow")
+        parts = pol.get("base2_exact_parts", ()) if lvl == 2 else ()
+        hq_c1 = (lambda t: t) if "c1" in parts else hq
+        hq_corr = (lambda t: t) if "corr" in parts else hq
+        hq_flow = (lambda t: t) if "flow" in parts else hq
+        c1f, c2 = feats[0][lvl - 1], hq(feats[1][lvl - 1])
+        c1 = hq_c1(c1f)
         if lvl == 6:
             xcat = hq(O.leaky_relu(O.correlation(c1, c2, 4, 1, 4, 1, 1, 1)))
         else:
             w = O.warp(c2, up_flow * O.WARP_SCALE[lvl])             # fused warp+correlation: the warped features are never stored
-            corr = hq(O.leaky_relu(O.correlation(c1, w, 4, 1, 4, 1, 1, 1)))
-            xcat = torch.cat((corr, c1, hq(up_flow), hq(up_feat)), 1)
+            corr = hq_corr(O.leaky_relu(O.correlation(hq(c1f) if lvl != 2 or not parts else c1f, w, 4, 1, 4, 1, 1, 1)))
+            xcat = torch.cat((corr, c1, hq_flow(up_flow), hq_flow(up_feat)), 1)
         for i in range(5):
             xcat = torch.cat((conv("conv%d_%d" % (lvl, i), xcat), xcat), 1)
         flow = conv("predict_flow%d" % lvl, xcat, act=False, mode="f")
@@ -189,6 +195,10 @@ WHATIF = [   # on top of fffffss
     ("+ base exact, conv2_0/1 exact", {"base2_exact": True, "noact": ("conv2_0", "conv2_1")}),
     ("+ base exact + dc_conv1 exact", {"base2_exact": True, "noact": ("dc_conv1",)}),
     ("+ base + conv2_* exact", {"base2_exact": True, "noact": ("conv2_",)}),
+    ("+ only corr of the base exact", {"base2_exact_parts": ("corr",)}),
+    ("+ only c1 of the base exact", {"base2_exact_parts": ("c1",)}),
+    ("+ only up_flow / up_feat exact", {"base2_exact_parts": ("flow",)}),
+    ("+ corr and c1 exact", {"base2_exact_parts": ("corr", "c1")}),
 ]
 
 
@@ -202,7 +212,10 @@ def main_whatif(which):
     with torch.no_grad():
         ref = forward_policy(sd, x, dict(zip(names, "fffffff")))
         print("== %s  mean|flow2| %.3f" % (which, ref.abs().mean().item()), flush=True)
+        only = sys.argv[3:]
         for name, extra in WHATIF:
+            if only and not any(o in name for o in only):
+                continue
             pol = dict(zip(names, "fffffss"))
             pol.update(extra)
             print("%-40s EPE flow2 %.3e" % (name, O.epe(forward_policy(sd, x, pol), ref)), flush=True)
