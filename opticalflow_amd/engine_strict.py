@@ -11,8 +11,9 @@ flops are:
     ``trunk2=False``: Winograd / direct MFMA fp32 kernels, 21 % of the network's multiplications).  Every warp therefore sees
     the same flow as the fp32 path: no discrete event is ever re-rolled, the remaining error is smooth;
   * the level-2 dense block, its flow head and the context network -- 79 % of the multiplications -- run in half precision on the
-    c8 kernels with SPLIT FILTERS (hi + lo halves of every filter, ops_f16.pack_conv3x3_f16(split=True): ~22-bit filters, twice
-    the MFMA passes, fp32 accumulation), fp32 flow head and fp32 ``flow2 = predict_flow2 + dc_conv7`` as in the fast plan.  What
+    c8 kernels, the layers with the largest share of the error budget with SPLIT FILTERS (hi + lo halves of every filter,
+    ops_f16.pack_conv3x3_f16(split=True): ~22-bit filters, twice the MFMA passes, fp32 accumulation; PLAIN_FILTERS below names the
+    layers that do without), fp32 flow head and fp32 ``flow2 = predict_flow2 + dc_conv7`` as in the fast plan.  What
     remains is the rounding of the activations those layers store (conv2_*, dc_conv*);
   * the level-2 BASE channels [corr 81 | c1 32 | up_flow 2 | up_feat 2] -- computed in fp32, read by all seven level-2 consumers
     -- are handed over with the rounding residual of corr and of the four flow channels stored as second channel sets
@@ -29,6 +30,7 @@ No autograd; ``flows()`` gives the training-mode 5-tuple (flow3..flow6 straight 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
@@ -37,6 +39,18 @@ from . import ops
 from . import ops_f16 as F16
 from .engine import CONTEXT, DENSE_OUT, LEAKY, PYRAMID_CH, PwcPlan
 from .engine_f16 import BASE_G, CORR_G, DENSE_G, _groups, context_filters, level_filters, prepare_params
+
+
+# Layers of the level-2 block / context network that run with PLAIN half filters (one MFMA pass instead of two).  Measured ladder
+# (batch 16 x 448x1024; EPE on the 1x448x1024 golden / the smooth KITTI-sized pair of the tests, the worst input they hold):
+#   every layer split                                      1739 pairs/s   6.5e-4 / 8.0e-4
+#   dc_conv4..6 plain                                      1783           6.8e-4 / 8.5e-4
+#   dc_conv4..6, conv2_3, conv2_4 plain      (default)     1857           7.1e-4 / 8.7e-4
+#   ... and dc_conv2, dc_conv3                             1897           8.0e-4 / 9.9e-4   (no margin left under 1e-3)
+# in line with the CPU what-if emulation (tests/f16_error_budget.py kitti whatif shipped: +0.25e-4 for conv2_3/2_4, +0.37e-4 for
+# dc_conv4..6, +1.1e-4 for dc_conv2..6).  PWC_STRICT_PLAIN (comma-separated layer names; "none" = every layer split) overrides it.
+_DEFAULT_PLAIN = "dc_conv4,dc_conv5,dc_conv6,conv2_3,conv2_4"
+PLAIN_FILTERS = frozenset(n for n in os.environ.get("PWC_STRICT_PLAIN", _DEFAULT_PLAIN).split(",") if n and n != "none")
 
 
 class PwcPlanStrict:
@@ -65,6 +79,7 @@ class PwcPlanStrict:
         self.dc7 = torch.zeros((B, 1, h2, w2, 8), device=device, dtype=torch.float32)
         self.flow_out = torch.empty((B, 2, h2, w2), device=device, dtype=torch.float32)
 
+        self.split: Dict[str, bool] = {}
         self.w: Dict[str, torch.Tensor] = {}
         self.b: Dict[str, torch.Tensor] = {}
         self.cin: Dict[str, int] = {}
@@ -81,13 +96,16 @@ class PwcPlanStrict:
                 w = w.clone()
                 w[:, rc0 - ps:rc0 + CORR_G * 8 - ps] = w[:, corr0 - ps:corr0 + CORR_G * 8 - ps]
                 w[:, rf0 - ps:rf0 + 8 - ps] = w[:, flow0 - ps:flow0 + 8 - ps]
-            self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float(), split=True)       # EVERY layer: hi + lo filters
+            # hi + lo filters, except on the layers PLAIN_FILTERS names (their what-if cost in EPE is recorded in the module docstring);
+            # the two flow heads (Cout 2: the residuals ride in the idle half of the cout tile) always keep them
+            self.split[name] = name in ("head2", "dc_conv7") or name not in PLAIN_FILTERS
+            self.w[name] = F16.pack_conv3x3_f16(w.contiguous().float(), split=self.split[name])
             self.b[name] = bias.contiguous().float()
             self.cin[name], self.cout[name] = w.shape[1], w.shape[0]
 
     def _conv(self, name, x, out, dilation=1, act=True):
         F16.conv3x3_f16(x, self.w[name], self.b[name], self.cin[name], self.cout[name], dilation=dilation,
-                        leaky_slope=LEAKY if act else None, out=out, out_f32=out.dtype == torch.float32, split_w=True)
+                        leaky_slope=LEAKY if act else None, out=out, out_f32=out.dtype == torch.float32, split_w=self.split[name])
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
         up, B = self.upper, self.B

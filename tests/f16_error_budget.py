@@ -112,7 +112,7 @@ def forward_policy(sd, x, pol, all_levels=False):
 
     def conv(name, t, stride=1, dilation=1, act=True, first=False, mode=None):
         key = name + ".0" if (name + ".0.weight") in sd else name
-        mode = mode or mode_of(name)
+        mode = mode or pol.get("layer_mode", {}).get(name) or mode_of(name)      # layer_mode: per-layer override of the block's policy
         w = sd[key + ".weight"].to(dt)
         if mode == "h" and not first:
             w = q(w)
@@ -199,6 +199,13 @@ WHATIF = [   # on top of fffffss
     ("+ only c1 of the base exact", {"base2_exact_parts": ("c1",)}),
     ("+ only up_flow / up_feat exact", {"base2_exact_parts": ("flow",)}),
     ("+ corr and c1 exact", {"base2_exact_parts": ("corr", "c1")}),
+    # the shipped strict plan (corr + flow residuals) and cheaper variants: which layers need their split (hi + lo) filters?
+    ("shipped: corr + flow residuals", {"base2_exact_parts": ("corr", "flow")}),
+    ("shipped, dc_conv2..6 plain half filters", {"base2_exact_parts": ("corr", "flow"), "layer_mode": {"dc_conv%d" % i: "h" for i in range(2, 7)}}),
+    ("shipped, dc_conv4..6 plain half filters", {"base2_exact_parts": ("corr", "flow"), "layer_mode": {"dc_conv%d" % i: "h" for i in range(4, 7)}}),
+    ("shipped, conv2_3 conv2_4 plain half filters", {"base2_exact_parts": ("corr", "flow"), "layer_mode": {"conv2_3": "h", "conv2_4": "h"}}),
+    ("shipped, only dc_conv1 conv2_0 conv2_1 split", {"base2_exact_parts": ("corr", "flow"), "layer_mode": dict({"dc_conv%d" % i: "h" for i in range(2, 7)}, conv2_2="h", conv2_3="h", conv2_4="h")}),
+    ("shipped, all level-2 / context filters plain half", {"base2_exact_parts": ("corr", "flow"), "layer_mode": dict({"dc_conv%d" % i: "h" for i in range(1, 7)}, conv2_0="h", conv2_1="h", conv2_2="h", conv2_3="h", conv2_4="h")}),
 ]
 
 
