@@ -46,7 +46,8 @@ from .engine_f16 import BASE_G, CORR_G, DENSE_G, _groups, context_filters, level
 #   every layer split                                      1739 pairs/s   6.5e-4 / 8.0e-4
 #   dc_conv4..6 plain                                      1783           6.8e-4 / 8.5e-4
 #   dc_conv4..6, conv2_3, conv2_4 plain      (default)     1857           7.1e-4 / 8.7e-4
-#   ... and dc_conv2, dc_conv3                             1897           8.0e-4 / 9.9e-4   (no margin left under 1e-3)
+#   default + conv2_2 / + conv2_1 / + conv2_0 / + dc_conv1   1915 / 1923 / 1901 / 1982     7.4-7.6e-4 / 9.1 / 9.1 / 9.5 / 9.3e-4
+#   default + dc_conv2, dc_conv3                           1897           8.0e-4 / 9.9e-4   (no margin left under 1e-3)
 # in line with the CPU what-if emulation (tests/f16_error_budget.py kitti whatif shipped: +0.25e-4 for conv2_3/2_4, +0.37e-4 for
 # dc_conv4..6, +1.1e-4 for dc_conv2..6).  PWC_STRICT_PLAIN (comma-separated layer names; "none" = every layer split) overrides it.
 _DEFAULT_PLAIN = "dc_conv4,dc_conv5,dc_conv6,conv2_3,conv2_4"
