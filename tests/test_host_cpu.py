@@ -358,3 +358,22 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     with pytest.raises(SystemExit) as ei:
         bench.main()
     assert not seen and "WORLD_SIZE=2" in str(ei.value.code)
+
+
+def test_strict_mode_default_filter_policy(monkeypatch):
+    """The strict half mode's default: plain (single-pass) filters on the five layers whose split buys the least accuracy, split (hi + lo)
+    filters everywhere else at level 2 / in the context network; PWC_STRICT_PLAIN overrides it ("none" = every layer split).  The measured
+    ladder behind the choice is in engine_strict.py and DESIGN.md 7a."""
+    import importlib
+    monkeypatch.delenv("PWC_STRICT_PLAIN", raising=False)
+    from opticalflow_amd import engine_strict
+    importlib.reload(engine_strict)
+    assert engine_strict.PLAIN_FILTERS == {"dc_conv4", "dc_conv5", "dc_conv6", "conv2_3", "conv2_4"}
+    monkeypatch.setenv("PWC_STRICT_PLAIN", "none")
+    importlib.reload(engine_strict)
+    assert engine_strict.PLAIN_FILTERS == frozenset()
+    monkeypatch.setenv("PWC_STRICT_PLAIN", "dc_conv6")
+    importlib.reload(engine_strict)
+    assert engine_strict.PLAIN_FILTERS == {"dc_conv6"}
+    monkeypatch.delenv("PWC_STRICT_PLAIN")
+    importlib.reload(engine_strict)
