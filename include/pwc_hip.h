@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 9
+#define PWC_ABI_VERSION 10
 
 /* element types */
 #define PWC_F32 0
@@ -65,6 +65,13 @@ extern "C" {
 
 int pwc_abi_version(void);
 const char *pwc_last_error(void);
+/* Run-time switches of the kernel selection (process-wide; tests and A/B benchmarks flip them instead of relying on an
+ * environment variable being read before first use).  Each option's default comes from the environment variable in brackets:
+ *   "conv_wino4" [PWC_CONV_WINO4] 1, "w4_tailsplit" [PWC_W4_TAILSPLIT] 1, "w4_smallsplit" [PWC_W4_SMALLSPLIT] 1,
+ *   "corr_pipe" [PWC_CORR_PIPE] 1, "corr_pipe_min_tiles" [PWC_CORR_PIPE_MIN_TILES] 1024, "warpcorr_window" [PWC_WARPCORR_WINDOW] 1.
+ * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */
+int pwc_set_option(const char *name, int value);
+int pwc_get_option(const char *name, int *value);
 /* Name and template arguments of the MFMA convolution variant this thread launched last -- what the tile cost
  * model picked for that layer: "conv3x3_mfma_kernel<MT, NT, stride, dilation, two-per-CU, 0>" (fp32) or
  * "conv3x3_f16_kernel<MT, NT, stride, dilation, ring, 0>" (fp16).  For benchmarks and profiles. */

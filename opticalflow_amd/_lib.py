@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
 LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
@@ -27,6 +27,8 @@ SIGNATURES = {
     "pwc_abi_version": (c_int, []),
     "pwc_last_error": (c_char_p, []),
     "pwc_last_conv_kernel": (c_char_p, []),
+    "pwc_set_option": (c_int, [c_char_p, c_int]),
+    "pwc_get_option": (c_int, [c_char_p, ctypes.POINTER(c_int)]),
     "pwc_corr_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_float,
                              c_int64, c_int64, c_int64, c_void_p]),
@@ -117,6 +119,17 @@ def load() -> ctypes.CDLL:
         raise PwcHipError("libpwc_hip.so ABI %d, binding expects %d -- rebuild" % (got, ABI_VERSION))
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int) -> None:
+    """pwc_set_option: flip a kernel-selection switch of the library at run time (see include/pwc_hip.h for the names)."""
+    check(load().pwc_set_option(name.encode(), int(value)), "pwc_set_option(%s)" % name)
+
+
+def get_option(name: str) -> int:
+    v = c_int(0)
+    check(load().pwc_get_option(name.encode(), ctypes.byref(v)), "pwc_get_option(%s)" % name)
+    return v.value
 
 
 def check(rc: int, what: str) -> None:

@@ -1,6 +1,9 @@
 // ABI bookkeeping for libpwc_hip.so: version and the thread-local error string.
 // Error convention mirrors the reference's "launcher returns a status, binding raises"
 // (correlation_cuda_kernel.cu:417-426 -> correlation_cuda.cc:81-83), minus the printf.
+#include <stdlib.h>
+#include <string.h>
+
 #include "pwc_common.h"
 
 namespace pwc {
@@ -24,7 +27,50 @@ void note_kernel(const char *name, int a, int b, int c, int d, int e, int f) {
     g_kargs[0] = a; g_kargs[1] = b; g_kargs[2] = c; g_kargs[3] = d; g_kargs[4] = e; g_kargs[5] = f;
 }
 
+// ---- run-time options ---------------------------------------------------------------------------------------
+// One table for the switches that used to be function-local `static const int knob = getenv(...)` (read
+// once at first use, so a test could only flip one if it ran before that use).  The environment variable still gives the
+// DEFAULT -- read the first time the option is looked at -- and pwc_set_option() overrides it at any time, for every thread.
+struct OptDesc { const char *name, *env; int dflt; };
+static const OptDesc kOpts[OPT_COUNT] = {
+    {"conv_wino4", "PWC_CONV_WINO4", 1},                  // F(4x4) route allowed (pwc_conv3x3_wino4_preferred)
+    {"w4_tailsplit", "PWC_W4_TAILSPLIT", 1},              // partial last round of an F(4x4) launch cut along Cin
+    {"w4_smallsplit", "PWC_W4_SMALLSPLIT", 1},            // launches that do not fill the chip cut along Cin (small batches)
+    {"corr_pipe", "PWC_CORR_PIPE", 1},                    // round-4 correlation kernels (pwc_corr_pipe.hip) for the large levels
+    {"corr_pipe_min_tiles", "PWC_CORR_PIPE_MIN_TILES", 1024},
+    {"warpcorr_window", "PWC_WARPCORR_WINDOW", 1},        // fused warp+correlation samples an LDS window (0: per-lane gathers only)
+};
+static std::atomic<int> g_opt_val[OPT_COUNT];
+static std::atomic<unsigned char> g_opt_set[OPT_COUNT];
+
+int option(Opt o) {
+    if (!g_opt_set[o].load(std::memory_order_acquire)) {
+        const char *e = getenv(kOpts[o].env);
+        g_opt_val[o].store((e && *e) ? atoi(e) : kOpts[o].dflt, std::memory_order_relaxed);
+        g_opt_set[o].store(1, std::memory_order_release);
+    }
+    return g_opt_val[o].load(std::memory_order_relaxed);
+}
+
 }  // namespace pwc
+
+extern "C" int pwc_set_option(const char *name, int value) {
+    if (!name) PWC_FAIL(PWC_EINVAL, "pwc_set_option: null name");
+    for (int o = 0; o < pwc::OPT_COUNT; ++o)
+        if (!strcmp(name, pwc::kOpts[o].name)) {
+            pwc::g_opt_val[o].store(value, std::memory_order_relaxed);
+            pwc::g_opt_set[o].store(1, std::memory_order_release);
+            return PWC_OK;
+        }
+    PWC_FAIL(PWC_EINVAL, "pwc_set_option: unknown option '%s'", name);
+}
+
+extern "C" int pwc_get_option(const char *name, int *value) {
+    if (!name || !value) PWC_FAIL(PWC_EINVAL, "pwc_get_option: null argument");
+    for (int o = 0; o < pwc::OPT_COUNT; ++o)
+        if (!strcmp(name, pwc::kOpts[o].name)) { *value = pwc::option((pwc::Opt)o); return PWC_OK; }
+    PWC_FAIL(PWC_EINVAL, "pwc_get_option: unknown option '%s'", name);
+}
 
 extern "C" const char *pwc_last_conv_kernel(void) {
     snprintf(pwc::g_kbuf, sizeof(pwc::g_kbuf), "%s<%d, %d, %d, %d, %d, %d>", pwc::g_kname, pwc::g_kargs[0], pwc::g_kargs[1],

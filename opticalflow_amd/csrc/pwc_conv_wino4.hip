@@ -591,14 +591,14 @@ inline int cout_padded4(int Cout) { return (Cout + 31) / 32 * 32; }
 // chip idle: 896 workgroups (the 64-cout layers of level 2) = 3.5 rounds cost 4, 448 = 1.75 cost 2 -- 12.5 % of those layers.  When the
 // last round is partial (and at least one full round precedes it) its tiles go into a second launch that cuts every tile into
 // two slices of the input channels, so that the slices fill the chip (128 tiles x 2 = 256 half-length workgroups); a small third
-// kernel adds the slices in a fixed order.  PWC_W4_TAILSPLIT=0 switches it off.
+// kernel adds the slices in a fixed order.  Option "w4_tailsplit" = 0 (pwc_set_option / PWC_W4_TAILSPLIT) switches it off.
 constexpr int kCUs = 256;
 struct TailPlan { int main_tiles, ksplit, cps; int64_t ws_bytes; };
 
 // The tail is made of the same (last) tile positions of EVERY image, so the result of an item does not depend on its slot in the batch.
 inline TailPlan wino4_tail_plan(int B, int64_t nblk, int ngroups, int nchunks, int Cout, int tile_px, int split2) {
     TailPlan p{(int)nblk, 1, nchunks, 0};
-    static const int knob = [] { const char *e = getenv("PWC_W4_TAILSPLIT"); return (e && *e) ? atoi(e) : 1; }();
+    const int knob = pwc::option(pwc::OPT_W4_TAILSPLIT);
     const int64_t nwg = nblk * ngroups, full = nwg / kCUs, rem = nwg - full * kCUs;
     if (!knob || split2 || full < 1 || rem == 0 || (kCUs % ngroups) != 0) return p;
     const int64_t main_tiles = full * kCUs / ngroups, tail = nblk - main_tiles;
@@ -666,10 +666,10 @@ static bool wino4_supported(int W, int dilation) { return dilation == 1 && W % 4
 
 // Does F(4x4,3x3) beat F(2x2,3x3) (pwc_conv3x3_wino_fwd) for this layer?  Rule measured at batch 16 (profiles/r03_wino4_layers.txt):
 // the tile groups are 8 or 16 rows x 64 columns, so the map must fill them, and the launch must cover the chip several times
-// over (a workgroup costs ~10 us outside its K loop).  PWC_CONV_WINO4=0 switches the route off (A/B runs; read once).
+// over (a workgroup costs ~10 us outside its K loop).  Option "conv_wino4" = 0 (pwc_set_option, default from PWC_CONV_WINO4) switches the route off (A/B runs).
 extern "C" int pwc_conv3x3_wino4_preferred(int B, int Cin, int H, int W, int Cout, int dilation) {
     if (B <= 0 || Cin < 32 || H <= 0 || W <= 0 || Cout < 32 || !wino4_supported(W, dilation)) return 0;
-    static const int knob = [] { const char *e = getenv("PWC_CONV_WINO4"); return (e && *e) ? atoi(e) : 1; }();
+    const int knob = pwc::option(pwc::OPT_CONV_WINO4);
     if (!knob) return 0;
     const int n32 = cout_padded4(Cout) / 32;
     const int gw = wino4_gw(W), gh = gw == 64 ? 4 : 8;                 // a tile group is gh rows x gw columns

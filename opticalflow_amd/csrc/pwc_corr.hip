@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "pwc_common.h"
+#include "pwc_corr_pipe.h"
 #include "pwc_warp_taps.h"
 
 // Cache policy (profiles/r01_corr_ablation.md): the 81-channel output is written once and not read again by this
@@ -729,6 +730,8 @@ int launch_corr(const void *in1, const void *in2, void *out, int B, int C, int H
                               reinterpret_cast<uintptr_t>(out)) & (uintptr_t)(va * elt - 1)) == 0;
         const int vec = (W % 4 == 0) && ptr_ok && (bs1 % 4 == 0) && (bs2 % 4 == 0) && (bso % 4 == 0);
         if constexpr (sizeof(T) == 4) {
+            if (vec && pwc::corr81_pipe_enabled() && pwc::corr81_pipe_fits(B, C, H, W))      // large levels: pwc_corr_pipe.hip
+                return pwc::launch_corr81_pipe(a, b, o, B, C, H, W, bs1, bs2, bso, scale, slope, do_leaky, st);
             if (vec && (int64_t)H * W * kCKd * 4 < 0x7fffffffLL) {
                 const int grid = (int)((nblk < kPersistentPerCU * 256) ? nblk : kPersistentPerCU * 256);
                 hipLaunchKernelGGL(corr81_dma_kernel<false>, dim3((unsigned)grid), dim3(kThreadsDma), 0, st,

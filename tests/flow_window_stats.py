@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Design study for the fused warp + correlation kernel (not a test): how large a source window of c2 around a tile has to be so
+that the bilinear taps of the tile's 16 x 40 halo pixels fall inside it, on the up_flow fields the decoder really produces
+(benchmark weights / inputs, CPU oracle).  Prints, per level and window margin, the share of halo pixels whose taps leave a
+window centred on the sample position of the tile's centre pixel -- those pixels take the kernel's gather path.
+
+usage: python tests/flow_window_stats.py [H W]      (default 448 1024)
+"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pwc_oracle as O  # noqa: E402
+from opticalflow_amd.weights import synthetic_state_dict  # noqa: E402
+
+
+def up_flows(sd, x):
+    """the (level, up_flow * scale) pairs PWCDCNet.forward warps with (PWCNet.py:212,226,240,256)"""
+    feats = []
+    for im in (x[:, :3], x[:, 3:]):
+        pyr, t = [], im
+        for i, (name, stride) in enumerate(O.PYRAMID):
+            t = O._conv(sd, name, t, stride=stride)
+            if i % 3 == 2:
+                pyr.append(t)
+        feats.append(pyr)
+    out = []
+    up_flow = up_feat = None
+    for lvl in (6, 5, 4, 3, 2):
+        c1, c2 = feats[0][lvl - 1], feats[1][lvl - 1]
+        if lvl == 6:
+            xcat = O.leaky_relu(O.correlation(c1, c2, 4, 1, 4, 1, 1, 1))
+        else:
+            out.append((lvl, up_flow * O.WARP_SCALE[lvl]))
+            w = O.warp(c2, up_flow * O.WARP_SCALE[lvl])
+            xcat = torch.cat((O.leaky_relu(O.correlation(c1, w, 4, 1, 4, 1, 1, 1)), c1, up_flow, up_feat), 1)
+        for i in range(5):
+            xcat = torch.cat((O._conv(sd, "conv%d_%d" % (lvl, i), xcat), xcat), 1)
+        flow = O._conv(sd, "predict_flow%d" % lvl, xcat, act=False)
+        if lvl > 2:
+            up_flow = O._deconv(sd, "deconv%d" % lvl, flow)
+            up_feat = O._deconv(sd, "upfeat%d" % lvl, xcat)
+    return out
+
+
+def coverage(flo, mx, my):
+    """share of halo pixels (16 x 40 around every 8 x 32 tile) with a tap outside the window
+    [floor(ixc) - 20 - mx, floor(ixc) + 21 + mx] x [floor(iyc) - 8 - my, floor(iyc) + 9 + my] of the tile's centre sample"""
+    B, _, H, W = flo.shape
+    xs = torch.arange(W, dtype=torch.float32).view(1, 1, W) + flo[:, 0]
+    ys = torch.arange(H, dtype=torch.float32).view(1, H, 1) + flo[:, 1]
+    ix = ((2 * xs / max(W - 1, 1) - 1 + 1) * W - 1) / 2
+    iy = ((2 * ys / max(H - 1, 1) - 1 + 1) * H - 1) / 2
+    fx, fy = torch.floor(ix), torch.floor(iy)
+    bad = tot = 0
+    for y0 in range(0, H, 8):
+        for x0 in range(0, W, 32):
+            yc, xc = min(y0 + 3, H - 1), min(x0 + 15, W - 1)
+            cx, cy = fx[:, yc, xc].view(B, 1, 1), fy[:, yc, xc].view(B, 1, 1)
+            # offset of the centre pixel inside the halo tile: column 19 (x0 - 4 + 19), row 7
+            ya, yb = max(y0 - 4, 0), min(y0 + 12, H)
+            xa, xb = max(x0 - 4, 0), min(x0 + 36, W)
+            tx, ty = fx[:, ya:yb, xa:xb], fy[:, ya:yb, xa:xb]
+            out = (tx < cx - 19 - mx) | (tx + 1 > cx + 21 + mx) | (ty < cy - 7 - my) | (ty + 1 > cy + 9 + my)
+            # taps wholly outside the image need no data (weight 0): they never force the gather path
+            out &= ~((tx + 1 < 0) | (tx > W - 1) | (ty + 1 < 0) | (ty > H - 1))
+            bad += int(out.sum())
+            tot += out.numel()
+    return bad / tot
+
+
+if __name__ == "__main__":
+    Himg, Wimg = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (448, 1024)
+    torch.set_num_threads(8)
+    man = O.state_dict_manifest()
+    for gain, seed in ((0.85, 0), (1.0, 0), (1.2, 0)):
+        sd = synthetic_state_dict(man, seed=seed, gain=gain, bias_std=0.02)
+        x = torch.rand(2, 6, Himg, Wimg, generator=torch.Generator().manual_seed(1234))
+        with torch.no_grad():
+            ups = up_flows(sd, x)
+        for lvl, f in ups:
+            dx = (f[:, :, :, 1:] - f[:, :, :, :-1]).abs().mean().item()
+            line = "gain %.2f level %d %3dx%3d mean|f| %6.2f px, max %6.1f, mean|df/dx| %.3f:" % (
+                gain, lvl, f.shape[2], f.shape[3], f.abs().mean().item(), f.abs().max().item(), dx)
+            for (mx, my) in ((1, 1), (2, 2), (3, 3), (4, 3), (4, 4), (6, 4)):
+                line += "  m%d,%d %.4f" % (mx, my, coverage(f, mx, my))
+            print(line, flush=True)
