@@ -38,6 +38,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"w4_smallsplit", "PWC_W4_SMALLSPLIT", 1},            // launches that do not fill the chip cut along Cin (small batches)
     {"corr_pipe", "PWC_CORR_PIPE", 1},                    // round-4 correlation kernels (pwc_corr_pipe.hip) for the large levels
     {"corr_pipe_min_tiles", "PWC_CORR_PIPE_MIN_TILES", 1024},
+    {"corr_roll", "PWC_CORR_ROLL", 1},                    // C <= 32: the rolling form (a workgroup walks down a column of tiles and keeps its in2 rows)
     {"warpcorr_window", "PWC_WARPCORR_WINDOW", 1},        // fused warp+correlation samples an LDS window (0: per-lane gathers only)
 };
 static std::atomic<int> g_opt_val[OPT_COUNT];

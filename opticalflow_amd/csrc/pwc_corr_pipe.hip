@@ -61,16 +61,18 @@ constexpr int kS1I = kS1F / 256, kS2I = kS2F / 256;       // 5 + 10 LDS-DMA wave
 constexpr int kDmaI = kS1I + kS2I;                        // instruction k < 5: in1, else in2
 constexpr int kR = 8;                                     // ring slots (the chunk count of a tile is a multiple: slots are static)
 constexpr int kLoadSplit = 7;                             // loader wave 0 issues instructions 0..6, loader wave 1 instructions 7..14
-constexpr int kMaxPieces = 11;                            // ceil(81 / 8) planes leave per ring step at most
-constexpr int kStageF = kMaxPieces * 256;                 // one stage buffer: 11 pieces of 64 lanes x 16 B
 constexpr unsigned kOOBv = 0x80000000u;
 static_assert((kR - 1) * (kDmaI - kLoadSplit) <= 63 && (kR - 1) * kLoadSplit <= 63, "vmcnt is a 6-bit counter");
 
-// wave roles (plain kernel): 0..8 fma, 9..10 loaders, 11 drainer -> 768 threads, three waves per SIMD, 168 registers
-constexpr int kWaveLoad0 = kND, kWaveDrain = kND + 2;
-constexpr int kThreadsPlain = 64 * (kND + 3);
+// wave roles (plain kernel): 0..8 fma, 9..10 loaders -> 704 threads, at most three waves per SIMD, 168 registers
+constexpr int kWaveLoad0 = kND;
+#ifdef PWC_PIPE_LOADERS4        // experiment: four loader waves (13 waves: 128 registers -- the fma waves spill; timing of the memory side only)
+constexpr int kThreadsPlain = 64 * (kND + 4);
+#else
+constexpr int kThreadsPlain = 64 * (kND + 2);
+#endif
 
-constexpr int kLdsPlain = (2 * kStageF + kR * (kS1F + kS2F)) * 4;
+constexpr int kLdsPlain = kR * (kS1F + kS2F) * 4;
 static_assert(kLdsPlain <= 160 * 1024, "LDS");
 
 // ds_read_b128 services a wave in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32: group k gets
@@ -123,34 +125,36 @@ struct PipeArgs {
     int64_t bs1, bs2, bso;
     float scale, slope;
     int do_leaky;
+    int seg_len, segs_per_strip, nseg;      // rolling kernel: vertical runs of tiles (see TileSeq)
 };
 
 // The 81 output planes of a tile leave during the NCH ring steps of the next one: step K takes the pieces q in
 // [81 K / NCH, 81 (K+1) / NCH), piece q = plane (q % 9) * 9 + q / 9 -- displacement column dx = q / 9 of fma wave q % 9, so that
-// every wave stages one piece (sometimes two) per step.  All of it is known at compile time.
+// every wave stores one piece (sometimes two) per step.  All of it is known at compile time.
 template <int NCH, int K> struct Share {
     static constexpr int q0 = 81 * K / NCH, q1 = 81 * (K + 1) / NCH;
-    static_assert(q1 - q0 <= kMaxPieces, "stage buffer");
 };
 
 // ---- fma waves ------------------------------------------------------------------------------------------------------
-struct HalfOps { float4 a[2], w0[2], w1[2], w2[2]; };     // the operands of two channels
+template <int LA> struct Ops { float4 a[LA], w0[LA], w1[LA], w2[LA]; };     // the operands of LA channels
 
-__device__ __forceinline__ void load_half(HalfOps &h, const float *s1, const float *s2, int c0) {
+template <int LA, int S2C>                      // S2C: floats between two channels of the in2 image (640: [c][16][40], 320: [c][8][40] halves)
+__device__ __forceinline__ void load_ops(Ops<LA> &h, const float *s1, const float *s2, int c0) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < LA; ++c) {
         h.a[c] = *reinterpret_cast<const float4 *>(s1 + (c0 + c) * kTH * kPitch);
-        h.w0[c] = *reinterpret_cast<const float4 *>(s2 + (c0 + c) * kS2Rows * kPitch);
-        h.w1[c] = *reinterpret_cast<const float4 *>(s2 + (c0 + c) * kS2Rows * kPitch + 4);
-        h.w2[c] = *reinterpret_cast<const float4 *>(s2 + (c0 + c) * kS2Rows * kPitch + 8);
+        h.w0[c] = *reinterpret_cast<const float4 *>(s2 + (c0 + c) * S2C);
+        h.w1[c] = *reinterpret_cast<const float4 *>(s2 + (c0 + c) * S2C + 4);
+        h.w2[c] = *reinterpret_cast<const float4 *>(s2 + (c0 + c) * S2C + 8);
     }
 }
 
 // pixel p even: pairs dx = (0,1)(2,3)(4,5)(6,7) + single dx 8;  p odd: pairs (1,2)(3,4)(5,6)(7,8) + single dx 0 -- so that every
 // in2 operand pair starts at an even window index (an aligned register pair straight out of ds_read_b128)
-__device__ __forceinline__ void fma_half(const HalfOps &h, f32x2 (&acc2)[kPX][4], float (&acc1)[kPX]) {
+template <int LA>
+__device__ __forceinline__ void fma_ops(const Ops<LA> &h, f32x2 (&acc2)[kPX][4], float (&acc1)[kPX]) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < LA; ++c) {
         const float av[kPX] = {h.a[c].x, h.a[c].y, h.a[c].z, h.a[c].w};
         const f32x2 wp[6] = {{h.w0[c].x, h.w0[c].y}, {h.w0[c].z, h.w0[c].w}, {h.w1[c].x, h.w1[c].y},
                              {h.w1[c].z, h.w1[c].w}, {h.w2[c].x, h.w2[c].y}, {h.w2[c].z, h.w2[c].w}};
@@ -167,51 +171,66 @@ __device__ __forceinline__ void fma_half(const HalfOps &h, f32x2 (&acc2)[kPX][4]
     }
 }
 
+template <int LA>
 struct FmaState {
     f32x2 acc2[kPX][4];
     float acc1[kPX];
-    float done[kND][kPX];        // the finished tile, finalised, waiting for its turn in the stage
-    HalfOps ha, hb;
+    float done[kND][kPX];        // the finished tile, finalised, leaving plane by plane
+    Ops<LA> ha, hb;
+    // where the finished tile goes: descriptor of its batch item's 81 planes, this lane's pixel offset, this wave's first plane
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;
+    int sbase, plane4;
 };
 
-// this wave's share of step K's pieces -> stage buffer (K & 1)
-template <int NCH, int K>
-__device__ __forceinline__ void stage_share(const FmaState &st, float *stage, int wave, int lane) {
+// this wave's share of step K's pieces: 16-byte stores straight from the second register set.  (A store costs its wave ~80 cycles
+// of issue -- 5 source registers x 64 lanes -- during which the other fma waves of the SIMD run; the nine waves' address/data paths
+// work in parallel, which one drainer wave's could not: staged through LDS the same stores took 880 cycles of every step.)
+template <int NCH, int K, int LA>
+__device__ __forceinline__ void store_share(const FmaState<LA> &st, int wave) {
     constexpr int q0 = Share<NCH, K>::q0, q1 = Share<NCH, K>::q1;
-    float *sb = stage + (K & 1) * kStageF + lane * 4;
 #pragma unroll
     for (int dx = q0 / 9; dx <= (q1 - 1) / 9; ++dx) {
         const int lo = q0 - 9 * dx > 0 ? q0 - 9 * dx : 0, hi = q1 - 9 * dx < 9 ? q1 - 9 * dx : 9;      // waves whose piece 9 dx + w is in [q0, q1)
         if (wave >= lo && wave < hi)
-            *reinterpret_cast<f32x4v *>(sb + (9 * dx + wave - q0) * 256) = (f32x4v){st.done[dx][0], st.done[dx][1], st.done[dx][2], st.done[dx][3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pwc::v4i32, (f32x4v){st.done[dx][0], st.done[dx][1], st.done[dx][2], st.done[dx][3]}),
+                                                   st.rs, (PWC_PIPE_EXP & 2) ? kOOBv : st.voff, st.sbase + dx * st.plane4, 2 /* nt */);
     }
 }
 
-// One ring step of the fma waves.  Half-step software pipeline: the operands of channels 0-1 of this chunk were requested
-// during the previous step (the loaders promise chunk s+1 at barrier B_s), so the fmas start right behind the barrier while
-// the reads of channels 2-3 are in flight; the reads of the NEXT chunk's first half go out between the two halves and stay in
-// flight across the barrier.  Straight-line code from the first read on: the compiler's counted lgkmcnt waits are exact.
-template <int NCH, int K>
-__device__ __forceinline__ void fma_step(FmaState &st, const PipeArgs &a, float *stage, const float *s1l, const float *s2l,
-                                         int wave, int lane, bool have_prev) {
-    if (have_prev) stage_share<NCH, K>(st, stage, wave, lane);
-    asm volatile("" ::: "memory");              // the stage writes stay AHEAD of the step's operand reads (see the barrier note)
-    constexpr int slot = K % kR, nslot = (K + 1) % kR;
-    load_half(st.hb, s1l + slot * kS1F, s2l + slot * kS2F, 2);
-    __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks these reads below the first half's fmas)
-    if (!(PWC_PIPE_EXP & 1)) fma_half(st.ha, st.acc2, st.acc1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_half(st.ha, s1l + nslot * kS1F, s2l + nslot * kS2F, 0);      // (behind the last chunk: a slot nobody needs)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(PWC_PIPE_EXP & 1)) fma_half(st.hb, st.acc2, st.acc1);
+template <int LA>
+__device__ __forceinline__ void pin_acc(FmaState<LA> &st) {
     // The fmas are register-only code: nothing ties them to the barrier, and with the steps unrolled hipcc moved ALL of a tile's
     // fmas behind its last barrier (operands spilled to scratch meanwhile).  An empty asm that reads and writes the accumulators
-    // pins this step's fmas above this point and the next step's below it.
+    // pins the fmas issued so far above this point and the later ones below it.
     asm volatile("" : "+v"(st.acc2[0][0]), "+v"(st.acc2[0][1]), "+v"(st.acc2[0][2]), "+v"(st.acc2[0][3]),
                       "+v"(st.acc2[1][0]), "+v"(st.acc2[1][1]), "+v"(st.acc2[1][2]), "+v"(st.acc2[1][3]),
                       "+v"(st.acc2[2][0]), "+v"(st.acc2[2][1]), "+v"(st.acc2[2][2]), "+v"(st.acc2[2][3]),
                       "+v"(st.acc2[3][0]), "+v"(st.acc2[3][1]), "+v"(st.acc2[3][2]), "+v"(st.acc2[3][3]),
                       "+v"(st.acc1[0]), "+v"(st.acc1[1]), "+v"(st.acc1[2]), "+v"(st.acc1[3]));
+}
+
+// One ring step of the fma waves, software-pipelined over groups of LA channels (LA = 2 at 168 registers, 1 at 128): the operands
+// of this chunk's first group were requested during the previous step (the loaders promise chunk s+1 at barrier B_s), so the fmas
+// start right behind the barrier; each group's fmas run while the next group's reads -- the last group: the NEXT chunk's first --
+// are in flight, and that look-ahead stays in flight across the barrier.  Straight-line code from the first read on: the
+// compiler's counted lgkmcnt waits are exact.  (With three fma waves on a SIMD the LDS phase and the fma phase of a step
+// otherwise add up.)
+template <int NCH, int K, int LA, int S2C>
+__device__ __forceinline__ void fma_step(FmaState<LA> &st, const PipeArgs &a, const float *s1l, const float *s2l, const float *s2n, int wave, bool have_prev) {
+    if (have_prev) store_share<NCH, K, LA>(st, wave);
+    constexpr int slot = K % kR, nslot = (K + 1) % kR;
+    constexpr int G = kCK / LA;                 // groups per chunk (even): group g lives in ha (g even) / hb (g odd)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        Ops<LA> &cur = (g & 1) ? st.hb : st.ha, &nxt = (g & 1) ? st.ha : st.hb;
+        if (g + 1 < G) load_ops<LA, S2C>(nxt, s1l + slot * kS1F, s2l + slot * kS2F, (g + 1) * LA);
+        else           load_ops<LA, S2C>(nxt, s1l + nslot * kS1F, (K == NCH - 1 ? s2n : s2l) + nslot * kS2F, 0);   // (behind the last chunk: a slot nobody needs)
+        __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the reads below the fmas they should overlap)
+        if (!(PWC_PIPE_EXP & 1)) fma_ops<LA>(cur, st.acc2, st.acc1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    pin_acc(st);
     if constexpr (K == NCH - 1) {
         // ---- tile finished: scale / LeakyReLU into the second register set; it leaves during the next tile's steps
 #pragma unroll
@@ -231,38 +250,49 @@ __device__ __forceinline__ void fma_step(FmaState &st, const PipeArgs &a, float 
             for (int m = 0; m < 4; ++m) st.acc2[p][m] = (f32x2){0.f, 0.f};
         }
     }
-    // Nothing to wait for before the barrier: the stage writes are OLDER than reads whose data the fmas above have consumed, and
-    // the LDS operations of a wave complete in order; the look-ahead reads stay in flight across the barrier.
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();               // (the look-ahead reads stay in flight across it)
     asm volatile("" ::: "memory");
 }
 
-template <int NCH, int K>
-__device__ __forceinline__ void fma_steps(FmaState &st, const PipeArgs &a, float *stage, const float *s1l, const float *s2l,
-                                          int wave, int lane, bool have_prev) {
+template <int NCH, int K, int LA, int S2C>
+__device__ __forceinline__ void fma_steps(FmaState<LA> &st, const PipeArgs &a, const float *s1l, const float *s2l, const float *s2n, int wave, bool have_prev) {
     if constexpr (K < NCH) {
-        fma_step<NCH, K>(st, a, stage, s1l, s2l, wave, lane, have_prev);
-        fma_steps<NCH, K + 1>(st, a, stage, s1l, s2l, wave, lane, have_prev);
+        fma_step<NCH, K, LA, S2C>(st, a, s1l, s2l, s2n, wave, have_prev);
+        fma_steps<NCH, K + 1, LA, S2C>(st, a, s1l, s2l, s2n, wave, have_prev);
     }
 }
 
-template <int NCH, int K>
-__device__ __forceinline__ void tail_steps(const FmaState &st, float *stage, int wave, int lane) {       // drain-only steps of the last tile
+template <int NCH, int K, int LA>
+__device__ __forceinline__ void tail_stores(const FmaState<LA> &st, int wave) {       // the last tile's planes
     if constexpr (K < NCH) {
-        stage_share<NCH, K>(st, stage, wave, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the stage writes are done before the barrier
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        tail_steps<NCH, K + 1>(st, stage, wave, lane);
+        store_share<NCH, K, LA>(st, wave);
+        tail_stores<NCH, K + 1, LA>(st, wave);
     }
 }
 
-template <int NCH>
-__device__ __forceinline__ void fma_wave(const PipeArgs &a, float *stage, const float *s1ring, const float *s2ring,
-                                         int wave, int lane, int my_tiles) {
+// where the tile the wave has just finished goes (its planes leave during the next tile's steps)
+template <int LA>
+__device__ __forceinline__ void set_destination_xy(FmaState<LA> &st, const PipeArgs &a, const TileXY &tl, int r, int g);
+
+template <int LA>
+__device__ __forceinline__ void set_destination(FmaState<LA> &st, const PipeArgs &a, int tile, int r, int g) {
+    set_destination_xy(st, a, tile_of(tile, a.nblk, a.tiles_x, a.tiles_y), r, g);
+}
+
+template <int LA>
+__device__ __forceinline__ void set_destination_xy(FmaState<LA> &st, const PipeArgs &a, const TileXY &tl, int r, int g) {
+    const int y = tl.y0 + r, x = tl.x0 + 4 * g;
+    st.voff = (y < a.H && x < a.W) ? (unsigned)(y * a.W + x) * 4u : kOOBv;
+    // (the SGPR offset takes part in the range check: num_records spans all 81 planes)
+    st.rs = __builtin_amdgcn_make_buffer_rsrc(pwc::uniform_ptr(a.out + (int64_t)((PWC_PIPE_EXP & 16) ? 0 : tl.b) * a.bso), 0,
+                                              __builtin_amdgcn_readfirstlane(81 * st.plane4), 0x00020000);
+}
+
+template <int NCH, int LA>
+__device__ __forceinline__ void fma_wave(const PipeArgs &a, const float *s1ring, const float *s2ring, int wave, int lane, int my_tiles) {
     int r, g;
     lane_to_rg(lane, r, g);
-    FmaState st;
+    FmaState<LA> st;
 #pragma unroll
     for (int p = 0; p < kPX; ++p) {
         st.acc1[p] = 0.f;
@@ -273,13 +303,22 @@ __device__ __forceinline__ void fma_wave(const PipeArgs &a, float *stage, const 
     for (int dx = 0; dx < kND; ++dx)
 #pragma unroll
         for (int p = 0; p < kPX; ++p) st.done[dx][p] = 0.f;
+    st.plane4 = a.H * a.W * 4;
+    st.sbase = wave * kND * st.plane4;
+    st.voff = kOOBv;
+    st.rs = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
+    const int stride = gridDim.x;
     const float *s1l = s1ring + r * kPitch + 4 * g, *s2l = s2ring + (r + wave) * kPitch + 4 * g;
     __builtin_amdgcn_s_barrier();              // B_0: chunks 0 and 1 are readable
     asm volatile("" ::: "memory");
-    load_half(st.ha, s1l, s2l, 0);
+    load_ops<LA, kS2Rows * kPitch>(st.ha, s1l, s2l, 0);
 #pragma unroll 1
-    for (int t = 0; t < my_tiles; ++t) fma_steps<NCH, 0>(st, a, stage, s1l, s2l, wave, lane, t > 0);
-    tail_steps<NCH, 0>(st, stage, wave, lane);
+    for (int t = 0; t < my_tiles; ++t) {
+        if (t > 0) set_destination(st, a, (int)blockIdx.x + (t - 1) * stride, r, g);
+        fma_steps<NCH, 0, LA, kS2Rows * kPitch>(st, a, s1l, s2l, s2l, wave, t > 0);
+    }
+    set_destination(st, a, (int)blockIdx.x + (my_tiles - 1) * stride, r, g);
+    tail_stores<NCH, 0, LA>(st, wave);
 }
 
 // ---- loader wave: instructions K0..K1 of the chunk's 15 LDS-DMA instructions --------------------------------------------
@@ -371,65 +410,235 @@ __device__ __forceinline__ void loader_wave(const PipeArgs &a, float *s1ring, fl
         if (k < nsteps) ld.issue(a, k, k, s1ring, s2ring, plane);
     wait_chunks_in_flight<I>(max(min(kR - 1, nsteps) - 2, 0));        // B_0 promises chunks 0 and 1
 #pragma unroll 1
-    for (int t = 0; t <= my_tiles; ++t) loader_steps<NCH, 0, K0, K1>(ld, a, s1ring, s2ring, lane, plane, t, nsteps, stride);
-    __builtin_amdgcn_s_barrier();                   // the drainer's last share
+    for (int t = 0; t < my_tiles; ++t) loader_steps<NCH, 0, K0, K1>(ld, a, s1ring, s2ring, lane, plane, t, nsteps, stride);
+    __builtin_amdgcn_s_barrier();                   // the barrier that ends the last step
 }
 
-// ---- drainer wave: stage -> global, 81 / NCH store instructions per ring step -----------------------------------------
-template <int NCH, int K>
-__device__ __forceinline__ void drain_steps(const float *stage, int lane, bool have_prev, __amdgpu_buffer_rsrc_t rs, unsigned voff, int plane4) {
-    if constexpr (K < NCH) {
-        __builtin_amdgcn_s_barrier();              // the pieces staged during step K are in stage[K & 1]
-        asm volatile("" ::: "memory");             // (s_barrier is IntrNoMem to the compiler: keep the stage reads below it)
-        if (have_prev && !(PWC_PIPE_EXP & 8)) {
-            constexpr int q0 = Share<NCH, K>::q0, q1 = Share<NCH, K>::q1;
-            const float *sb = stage + (K & 1) * kStageF + lane * 4;
-            f32x4v v[q1 - q0];
+// =====================================================================================================================
+// ROLLING form (C <= 32: the in2 halo tiles of all eight chunks fit in LDS together).
+// What bounds the ring form is not HBM but the CU's vector-memory pipeline: it moves ~12 bytes per clock, LDS-DMA fetches and
+// stores one after the other, and L2 hits cost the same as misses (profiles/r04_corr_notes.md: 120 KB of LDS-DMA + 81 KB of stores
+// per tile = 7.8 us, x 7 tiles).  80 of those 120 KB are the in2 halo tile, and half of its rows were in LDS a moment ago: the
+// tile above needed them.  So a workgroup walks DOWN a column of tiles and keeps the in2 rows it has:
+//   * in2 lives as [chunk k][half][4 channels][8 rows][40]; halo row i of the run's tile number ti is in half ((i >> 3) + ti) & 1:
+//     the lower half of a tile is the upper half of the next, and only 8 new rows per channel are fetched (5 LDS-DMA instructions
+//     per chunk instead of 10; the first tile of a run fetches both halves);
+//   * chunk k of tile n+1 (in1 and in2) is fetched into exactly what chunk k of tile n has vacated, right after the step that
+//     multiplied it: every fetch is issued NCH - 1 = 7 steps before it is needed -- the ring IS one whole tile.
+struct TileSeq {            // this workgroup's tiles: runs ("segments") of seg_len tiles down one column of one image
+    int seg, ti, cnt;       // current segment, tile number inside it, tiles in it
+    TileXY xy;
+    __device__ __forceinline__ void load_segment(const PipeArgs &a) {
+        int sg = seg;
+        if ((a.nseg & 7) == 0) sg = (sg & 7) * (a.nseg >> 3) + (sg >> 3);     // segments running together on one XCD: neighbouring columns
+        const int tx = sg % a.tiles_x;
+        sg /= a.tiles_x;
+        const int part = sg % a.segs_per_strip;
+        xy.b = sg / a.segs_per_strip;
+        xy.x0 = tx * kTW;
+        xy.y0 = part * a.seg_len * kTH;
+        cnt = min(a.seg_len, a.tiles_y - part * a.seg_len);
+        ti = 0;
+    }
+    __device__ __forceinline__ void start(const PipeArgs &a) { seg = blockIdx.x; load_segment(a); }
+    __device__ __forceinline__ bool valid(const PipeArgs &a) const { return seg < a.nseg; }
+    __device__ __forceinline__ void advance(const PipeArgs &a) {
+        if (++ti < cnt) { xy.y0 += kTH; return; }
+        seg += gridDim.x;
+        if (seg < a.nseg) load_segment(a);
+    }
+};
+
+__device__ __forceinline__ int roll_my_tiles(const PipeArgs &a) {
+    int n = 0;
+    for (int sg = blockIdx.x; sg < a.nseg; sg += gridDim.x) {
+        int s2 = sg;
+        if ((a.nseg & 7) == 0) s2 = (s2 & 7) * (a.nseg >> 3) + (s2 >> 3);
+        const int part = (s2 / a.tiles_x) % a.segs_per_strip;
+        n += min(a.seg_len, a.tiles_y - part * a.seg_len);
+    }
+    return n;
+}
+
+constexpr int kHalfF = kCK * 8 * kPitch;          // 1280 floats: four channels x eight rows of the in2 halo tile
+constexpr int kHalfI = kHalfF / 256;              // 5 LDS-DMA instructions
+constexpr int kRollNCH = 8;
+constexpr int kLdsRoll = kRollNCH * (kS1F + 2 * kHalfF) * 4;       // 120 KB
+constexpr int kThreadsRoll = 64 * (kND + 2);      // nine fma waves, loader A (in1 + upper in2 half of a run's first tile), loader B (new in2 rows)
+
+// Loader A: WHICH = 0 -> in1 (8 rows of the tile) + E = the upper half (halo rows 0-7) when the tile starts a run;
+// loader B: WHICH = 1 -> the lower half (halo rows 8-15): the 8 new rows.
+template <int WHICH>
+struct RollLoader {
+    unsigned off[kHalfI], offE[kHalfI];
+    const float *ip;          // in1 (A) / in2 (B) of the tile's batch item
+    const float *ipE;         // in2 for E (A only)
+    bool first;               // the tile being fetched starts a run
+    int half;                 // in2 half the new rows go to (B); E goes to the other one (A)
+
+    __device__ __forceinline__ void new_tile(const PipeArgs &a, const TileSeq &sq, int lane, int plane) {
+        first = (sq.ti == 0);
+        half = (1 + sq.ti) & 1;
 #pragma unroll
-            for (int j = 0; j < q1 - q0; ++j) v[j] = *reinterpret_cast<const f32x4v *>(sb + j * 256);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // stage reads done before the barrier that frees the buffer
-#pragma unroll
-            for (int j = 0; j < q1 - q0; ++j) {
-                const int q = q0 + j, ch = (q % 9) * 9 + q / 9;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pwc::v4i32, v[j]), rs, (PWC_PIPE_EXP & 2) ? kOOBv : voff,
-                                                       ch * plane4, (PWC_PIPE_EXP & 64) ? 0 : (PWC_PIPE_EXP & 128) ? 17 : 2 /* nt */);
+        for (int k = 0; k < kHalfI; ++k) {
+            const int p = k * 64 + lane;
+            const int c = p / 80, row = (p / 10) % 8, q = p % 10;
+            if (WHICH == 0) {
+                const int iy = sq.xy.y0 + row, ix = sq.xy.x0 + 4 * q;
+                const bool ok = (q < kTG) && (iy < a.H) && (ix < a.W);
+                off[k] = ok ? (unsigned)(c * plane + iy * a.W + ix) * 4u : kOOBv;
+                const int ey = sq.xy.y0 - kD + row, ex = sq.xy.x0 - kD + 4 * q;
+                const bool eok = (ey >= 0) && (ey < a.H) && (ex >= 0) && (ex < a.W);
+                offE[k] = eok ? (unsigned)(c * plane + ey * a.W + ex) * 4u : kOOBv;
+            } else {
+                const int iy = sq.xy.y0 - kD + 8 + row, ix = sq.xy.x0 - kD + 4 * q;
+                const bool ok = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
+                off[k] = ok ? (unsigned)(c * plane + iy * a.W + ix) * 4u : kOOBv;
             }
         }
-        drain_steps<NCH, K + 1>(stage, lane, have_prev, rs, voff, plane4);
+        const int b = (PWC_PIPE_EXP & 32) ? 0 : sq.xy.b;
+        ip = (WHICH == 0 ? a.in1 + (int64_t)b * a.bs1 : a.in2 + (int64_t)b * a.bs2);
+        ipE = a.in2 + (int64_t)b * a.bs2;
+    }
+
+    // chunk k of the tile described by new_tile()
+    __device__ __forceinline__ void issue(const PipeArgs &a, int k, float *s1ring, float *in2buf, int plane) {
+        const int c0 = k * kCK;
+        const int nbytes = min(kCK, a.C - c0) * plane * 4;        // channels past C fail the range check: zeros
+        const pwc::v4i32 rs = pwc::make_rsrc(ip + (int64_t)c0 * plane, nbytes);
+        float *dst = (WHICH == 0) ? s1ring + k * kS1F : in2buf + k * 2 * kHalfF + half * kHalfF;
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(dst));
+#pragma unroll
+        for (int i = 0; i < kHalfI; ++i) pwc::dma_b128(rs, base + i * 1024, off[i]);
+        if (WHICH == 0 && first) {
+            const pwc::v4i32 rsE = pwc::make_rsrc(ipE + (int64_t)c0 * plane, nbytes);
+            const unsigned baseE = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(in2buf + k * 2 * kHalfF + (1 - half) * kHalfF));
+#pragma unroll
+            for (int i = 0; i < kHalfI; ++i) pwc::dma_b128(rsE, baseE + i * 1024, offE[i]);
+        }
+    }
+};
+
+template <int K, int WHICH>
+__device__ __forceinline__ void roll_loader_steps(RollLoader<WHICH> &ld, const PipeArgs &a, float *s1ring, float *in2buf, int plane,
+                                                  bool have_next, int steps_left) {
+    if constexpr (K < kRollNCH) {
+        __builtin_amdgcn_s_barrier();              // B_s: step s = (tile n, chunk K) begins; chunk K-1's place is free
+        constexpr int kv = (K + kRollNCH - 1) % kRollNCH;       // the chunk vacated by the step that has just ended
+        // (K = 0: chunk 7 of the PREVIOUS tile was vacated -- its successor is chunk 7 of THIS tile, fetched from the previous
+        // tile's loop with that tile's new_tile(); so the fetches of this loop are chunks 0..6 of tile n+1 at K = 1..7, and chunk 7
+        // of tile n+1 at K = 0 of the next loop: see roll_loader_wave)
+        if (K >= 1 && have_next && !(PWC_PIPE_EXP & 4)) ld.issue(a, kv, s1ring, in2buf, plane);
+        // the fetch needed at B_{s+1} (chunk of step s+2) has landed: at most NCH-3 younger fetches of 5 instructions are outstanding
+        // (a run's first tile makes loader A's 10 -- then this waits for a little more than it has to)
+        const int younger = min(kRollNCH - 3, steps_left - 3 - K);        // fetches issued after the one for step s+2
+        wait_chunks_in_flight<kHalfI>(max(younger, 0));
+        roll_loader_steps<K + 1, WHICH>(ld, a, s1ring, in2buf, plane, have_next, steps_left);
     }
 }
 
-template <int NCH>
-__device__ __forceinline__ void drainer_wave(const PipeArgs &a, const float *stage, int lane, int my_tiles) {
-    const int plane4 = a.H * a.W * 4;
-    const int stride = gridDim.x;
+template <int WHICH>
+__device__ __forceinline__ void roll_loader_wave(const PipeArgs &a, float *s1ring, float *in2buf, int lane, int my_tiles) {
+    __builtin_amdgcn_s_setprio(3);
+    const int plane = a.H * a.W;
+    TileSeq sq;
+    sq.start(a);
+    RollLoader<WHICH> ld;
+    ld.new_tile(a, sq, lane, plane);
+    // prologue: the whole first tile.  Loader A issues 8 x 10 instructions: six chunks, a wait, the other two (vmcnt is a 6-bit counter)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ld.issue(a, k, s1ring, in2buf, plane);
+    if (WHICH == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * 2 * kHalfI) : "memory");        // chunks 0, 1 have landed
+    ld.issue(a, 6, s1ring, in2buf, plane);
+    ld.issue(a, 7, s1ring, in2buf, plane);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * kHalfI) : "memory");      // B_0 promises chunks 0 and 1 (loader B: 6 x 5 younger; A: more than needed)
+    // tile loop: during tile n the chunks 0..6 of tile n+1 are fetched at K = 1..7 and chunk 7 of tile n at K = 0 (vacated by tile n-1)
+    bool pending7 = false;      // chunk 7 of the tile `ld` describes is still to be fetched (at K = 0 of the next loop)
+#pragma unroll 1
+    for (int n = 0; n < my_tiles; ++n) {
+        // K = 0 belongs to the tile described by the loader state of the previous loop: fetch its chunk 7 first
+        __builtin_amdgcn_s_barrier();              // B_s, s = (n, 0)
+        if (pending7 && !(PWC_PIPE_EXP & 4)) ld.issue(a, kRollNCH - 1, s1ring, in2buf, plane);
+        const int steps_left = (my_tiles - n) * kRollNCH;               // ring steps from (n, 0) to the end
+        {
+            const int younger = min(kRollNCH - 3, steps_left - 3);
+            wait_chunks_in_flight<kHalfI>(max(younger, 0));
+        }
+        const bool have_next = (n + 1 < my_tiles);
+        if (have_next) { sq.advance(a); ld.new_tile(a, sq, lane, plane); }
+        pending7 = have_next;
+        roll_loader_steps<1, WHICH>(ld, a, s1ring, in2buf, plane, have_next, steps_left);
+    }
+    __builtin_amdgcn_s_barrier();                   // the barrier that ends the last step
+}
+
+template <int LA>
+__device__ __forceinline__ void roll_fma_wave(const PipeArgs &a, const float *s1ring, const float *in2buf, int wave, int lane, int my_tiles) {
     int r, g;
     lane_to_rg(lane, r, g);
-    unsigned voff = kOOBv;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
-    __builtin_amdgcn_s_barrier();                  // B_0
-#pragma unroll 1
-    for (int t = 0; t <= my_tiles; ++t) {          // during tile slot t (my_tiles = the drain-only tail) the planes of tile t-1 leave
-        if (t >= 1) {
-            const TileXY tl = tile_of((int)blockIdx.x + (t - 1) * stride, a.nblk, a.tiles_x, a.tiles_y);
-            const int y = tl.y0 + r, x = tl.x0 + 4 * g;
-            voff = (y < a.H && x < a.W) ? (unsigned)(y * a.W + x) * 4u : kOOBv;
-            if (PWC_PIPE_EXP & 2048) voff = (unsigned)(((tl.y0 / kTH) * a.tiles_x + tl.x0 / kTW) * 256 + r * 32 + 4 * g) * 4u;   // experiment: 1 KB contiguous per plane and tile
-            // (the SGPR offset takes part in the range check: num_records spans all 81 planes)
-            rs = __builtin_amdgcn_make_buffer_rsrc(pwc::uniform_ptr(a.out + (int64_t)((PWC_PIPE_EXP & 16) ? 0 : tl.b) * a.bso), 0,
-                                                   __builtin_amdgcn_readfirstlane(81 * plane4), 0x00020000);
-        }
-        drain_steps<NCH, 0>(stage, lane, t >= 1, rs, voff, plane4);
+    FmaState<LA> st;
+#pragma unroll
+    for (int p = 0; p < kPX; ++p) {
+        st.acc1[p] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) st.acc2[p][m] = (f32x2){0.f, 0.f};
     }
+#pragma unroll
+    for (int dx = 0; dx < kND; ++dx)
+#pragma unroll
+        for (int p = 0; p < kPX; ++p) st.done[dx][p] = 0.f;
+    st.plane4 = a.H * a.W * 4;
+    st.sbase = wave * kND * st.plane4;
+    st.voff = kOOBv;
+    st.rs = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
+    const float *s1l = s1ring + r * kPitch + 4 * g;
+    // this lane's halo row i = r + wave lives in half ((i >> 3) + ti) & 1 of every chunk's in2 block
+    const int i = r + wave;
+    const float *s2e = in2buf + (i >> 3) * kHalfF + (i & 7) * kPitch + 4 * g;            // run tile number even
+    const float *s2o = in2buf + (1 - (i >> 3)) * kHalfF + (i & 7) * kPitch + 4 * g;      // odd
+    TileSeq sq;
+    sq.start(a);
+    TileXY prev = sq.xy;
+    __builtin_amdgcn_s_barrier();              // B_0: chunks 0 and 1 are readable
+    asm volatile("" ::: "memory");
+    load_ops<LA, 8 * kPitch>(st.ha, s1l, s2e, 0);
+#pragma unroll 1
+    for (int n = 0; n < my_tiles; ++n) {
+        if (n > 0) set_destination_xy(st, a, prev, r, g);
+        prev = sq.xy;
+        const float *s2l = (sq.ti & 1) ? s2o : s2e;
+        sq.advance(a);                                                  // (past the last tile: unused)
+        const float *s2n = (sq.ti & 1) ? s2o : s2e;
+        fma_steps<kRollNCH, 0, LA, 8 * kPitch>(st, a, s1l, s2l, s2n, wave, n > 0);
+    }
+    set_destination_xy(st, a, prev, r, g);
+    tail_stores<kRollNCH, 0, LA>(st, wave);
+}
+
+__global__ void __launch_bounds__(kThreadsRoll, 3)
+corr81_roll_kernel(PipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s1ring = smem;                            // [8 chunks][kS1F]
+    float *in2buf = s1ring + kRollNCH * kS1F;        // [8 chunks][2 halves][kHalfF]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int my_tiles = roll_my_tiles(a);
+    if (wave == kND)          roll_loader_wave<0>(a, s1ring, in2buf, lane, my_tiles);
+    else if (wave == kND + 1) roll_loader_wave<1>(a, s1ring, in2buf, lane, my_tiles);
+    else                      roll_fma_wave<2>(a, s1ring, in2buf, wave, lane, my_tiles);
 }
 
 // =====================================================================================================================
 template <int NCH>
+#ifdef PWC_PIPE_LOADERS4
+__global__ void __launch_bounds__(kThreadsPlain, 4)
+#else
 __global__ void __launch_bounds__(kThreadsPlain, 3)
+#endif
 corr81_pipe_kernel(PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *stage = smem;                             // [2][kStageF]
-    float *s1ring = smem + 2 * kStageF;              // [kR][kS1F]
+    float *s1ring = smem;                            // [kR][kS1F]
     float *s2ring = s1ring + kR * kS1F;              // [kR][kS2F]
     static_assert(NCH % kR == 0, "static ring slots");
 
@@ -438,15 +647,21 @@ corr81_pipe_kernel(PipeArgs a) {
     const int lane = tid & 63;
     const int stride = gridDim.x;
     const int my_tiles = (a.nblk - (int)blockIdx.x + stride - 1) / stride;
-    // barriers of every wave: B_0, one per ring step of its tiles, NCH drain-only steps = my_tiles NCH + NCH + 1
+    // barriers of every wave: B_0 and one at the end of every ring step of its tiles
 
+#ifdef PWC_PIPE_LOADERS4
+    if (wave == kWaveLoad0)          loader_wave<NCH, 0, 4>(a, s1ring, s2ring, lane, my_tiles);
+    else if (wave == kWaveLoad0 + 1) loader_wave<NCH, 4, 8>(a, s1ring, s2ring, lane, my_tiles);
+    else if (wave == kWaveLoad0 + 2) loader_wave<NCH, 8, 12>(a, s1ring, s2ring, lane, my_tiles);
+    else if (wave == kWaveLoad0 + 3) loader_wave<NCH, 12, kDmaI>(a, s1ring, s2ring, lane, my_tiles);
+#else
     if (wave == kWaveLoad0)          loader_wave<NCH, 0, kLoadSplit>(a, s1ring, s2ring, lane, my_tiles);
     else if (wave == kWaveLoad0 + 1) loader_wave<NCH, kLoadSplit, kDmaI>(a, s1ring, s2ring, lane, my_tiles);
-    else if (wave == kWaveDrain)     drainer_wave<NCH>(a, stage, lane, my_tiles);
-    else                             fma_wave<NCH>(a, stage, s1ring, s2ring, wave, lane, my_tiles);
+#endif
+    else                             fma_wave<NCH, 2>(a, s1ring, s2ring, wave, lane, my_tiles);
 }
 
-pwc::LdsAttrOnce g_lds_plain8, g_lds_plain16;
+pwc::LdsAttrOnce g_lds_plain8, g_lds_plain16, g_lds_roll;
 
 }  // namespace
 
@@ -467,7 +682,21 @@ int launch_corr81_pipe(const float *in1, const float *in2, float *out, int B, in
     const int nblk = B * tiles_x * tiles_y;
     const int nch = (C + kCK - 1) / kCK;
     const int grid = nblk < 256 ? nblk : 256;       // one workgroup per CU (its LDS does not admit two)
-    const PipeArgs a{in1, in2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky};
+    PipeArgs a{in1, in2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0};
+    if (nch == 8 && option(OPT_CORR_ROLL)) {
+        // runs of seg_len tiles down a column: as long as possible while the runs still cover the chip about once
+        int seg_len = nblk / 256;
+        if (seg_len < 1) seg_len = 1;
+        if (seg_len > tiles_y) seg_len = tiles_y;
+        a.seg_len = seg_len;
+        a.segs_per_strip = (tiles_y + seg_len - 1) / seg_len;
+        a.nseg = B * tiles_x * a.segs_per_strip;
+        const int groll = a.nseg < 256 ? a.nseg : 256;
+        int rc = ensure_lds_attr(g_lds_roll, reinterpret_cast<const void *>(corr81_roll_kernel), kLdsRoll, "corr81_roll_kernel");
+        if (rc != PWC_OK) return rc;
+        hipLaunchKernelGGL(corr81_roll_kernel, dim3((unsigned)groll), dim3(kThreadsRoll), kLdsRoll, st, a);
+        return check_launch("corr81_roll_kernel");
+    }
     if (nch == 8) {
         int rc = ensure_lds_attr(g_lds_plain8, reinterpret_cast<const void *>(corr81_pipe_kernel<8>), kLdsPlain, "corr81_pipe_kernel<8>");
         if (rc != PWC_OK) return rc;
