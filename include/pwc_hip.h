@@ -68,8 +68,9 @@ const char *pwc_last_error(void);
 /* Run-time switches of the kernel selection (process-wide; tests and A/B benchmarks flip them instead of relying on an
  * environment variable being read before first use).  Each option's default comes from the environment variable in brackets:
  *   "conv_wino4" [PWC_CONV_WINO4] 1, "w4_tailsplit" [PWC_W4_TAILSPLIT] 1, "w4_smallsplit" [PWC_W4_SMALLSPLIT] 1,
- *   "corr_pipe" [PWC_CORR_PIPE] 1, "corr_pipe_min_tiles" [PWC_CORR_PIPE_MIN_TILES] 1024, "corr_roll" [PWC_CORR_ROLL] 1,
- *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1.
+ *   "corr_pipe" [PWC_CORR_PIPE] 0 (plain correlation on the round-4 pipelined kernels), "corr_roll" [PWC_CORR_ROLL] 1 (their rolling form),
+ *   "corr_pipe_min_tiles" [PWC_CORR_PIPE_MIN_TILES] 1024 (8x32 tiles a launch needs for the round-4 kernels),
+ *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off).
  * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */
 int pwc_set_option(const char *name, int value);
 int pwc_get_option(const char *name, int *value);

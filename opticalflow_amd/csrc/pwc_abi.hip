@@ -36,10 +36,11 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"conv_wino4", "PWC_CONV_WINO4", 1},                  // F(4x4) route allowed (pwc_conv3x3_wino4_preferred)
     {"w4_tailsplit", "PWC_W4_TAILSPLIT", 1},              // partial last round of an F(4x4) launch cut along Cin
     {"w4_smallsplit", "PWC_W4_SMALLSPLIT", 1},            // launches that do not fill the chip cut along Cin (small batches)
-    {"corr_pipe", "PWC_CORR_PIPE", 1},                    // round-4 correlation kernels (pwc_corr_pipe.hip) for the large levels
+    {"corr_pipe", "PWC_CORR_PIPE", 0},                    // PLAIN correlation on the round-4 pipelined / rolling kernels (pwc_corr_pipe.hip): parity with
+                                                          // the round-2 kernel at level 2, slower at level 3 -- opt-in (profiles/r04_corr_notes.md)
     {"corr_pipe_min_tiles", "PWC_CORR_PIPE_MIN_TILES", 1024},
     {"corr_roll", "PWC_CORR_ROLL", 1},                    // C <= 32: the rolling form (a workgroup walks down a column of tiles and keeps its in2 rows)
-    {"warpcorr_window", "PWC_WARPCORR_WINDOW", 1},        // fused warp+correlation samples an LDS window (0: per-lane gathers only)
+    {"warpcorr_window", "PWC_WARPCORR_WINDOW", 1},        // fused warp+correlation on the LDS-window kernel: 1 = C <= 32 (level 2), 2 = also C <= 64, 0 = round-2 kernel
 };
 static std::atomic<int> g_opt_val[OPT_COUNT];
 static std::atomic<unsigned char> g_opt_set[OPT_COUNT];

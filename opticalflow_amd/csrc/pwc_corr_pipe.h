@@ -14,4 +14,10 @@ bool corr81_pipe_enabled();
 int launch_corr81_pipe(const float *in1, const float *in2, float *out, int B, int C, int H, int W,
                        int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky, hipStream_t st);
 
+// fused warp + correlation on the LDS-window kernel: geometry rule + option "warpcorr_window"
+bool warp_corr81_pipe_fits(int B, int C, int H, int W);
+int launch_warp_corr81_pipe(const float *in1, const float *x2, const float *flo, float *out, int B, int C, int H, int W,
+                            int64_t bs1, int64_t bs2, int64_t bsf, int64_t bso, float flow_scale, int align_corners, float thr,
+                            float scale, float slope, int do_leaky, hipStream_t st);
+
 }  // namespace pwc

@@ -39,7 +39,8 @@
                             // 2 = stores go out with out-of-range offsets, 4 = no LDS-DMA after the prologue, 8 = the drainer only keeps the barriers,
                             // 16 = every batch item is written over item 0 (cache-resident output), 32 = every batch item reads item 0,
                             // 64 = default-policy stores instead of nt, 128 = sc0 sc1 (write-through) stores, 256 = only half of the in2 rows are fetched, 512 = in1 is not fetched,
-                            // 1024 / 2048 = in1 is read / the output is written as 1 KB contiguous per channel (plane) and tile
+                            // 1024 = in1 is read as 1 KB contiguous per channel and tile, 2048 = (fused) every pixel takes the gather path,
+                            // 4096 = (fused) the producers only keep the barriers
 #endif
 
 namespace {
@@ -126,6 +127,10 @@ struct PipeArgs {
     float scale, slope;
     int do_leaky;
     int seg_len, segs_per_strip, nseg;      // rolling kernel: vertical runs of tiles (see TileSeq)
+    const float *flo;                       // fused kernel: [B,2,H,W] flow (u, v), its batch stride, scale, mask threshold, sampling mode
+    int64_t bsf;
+    float flow_scale, thr;
+    int align_corners;
 };
 
 // The 81 output planes of a tile leave during the NCH ring steps of the next one: step K takes the pieces q in
@@ -216,16 +221,17 @@ __device__ __forceinline__ void pin_acc(FmaState<LA> &st) {
 // are in flight, and that look-ahead stays in flight across the barrier.  Straight-line code from the first read on: the
 // compiler's counted lgkmcnt waits are exact.  (With three fma waves on a SIMD the LDS phase and the fma phase of a step
 // otherwise add up.)
-template <int NCH, int K, int LA, int S2C>
+template <int NCH, int K, int LA, int S2C, int S2R = kR>
 __device__ __forceinline__ void fma_step(FmaState<LA> &st, const PipeArgs &a, const float *s1l, const float *s2l, const float *s2n, int wave, bool have_prev) {
     if (have_prev) store_share<NCH, K, LA>(st, wave);
     constexpr int slot = K % kR, nslot = (K + 1) % kR;
+    constexpr int slot2 = K % S2R, nslot2 = (K + 1) % S2R;       // the in2 image may live in a shorter ring (fused kernel)
     constexpr int G = kCK / LA;                 // groups per chunk (even): group g lives in ha (g even) / hb (g odd)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         Ops<LA> &cur = (g & 1) ? st.hb : st.ha, &nxt = (g & 1) ? st.ha : st.hb;
-        if (g + 1 < G) load_ops<LA, S2C>(nxt, s1l + slot * kS1F, s2l + slot * kS2F, (g + 1) * LA);
-        else           load_ops<LA, S2C>(nxt, s1l + nslot * kS1F, (K == NCH - 1 ? s2n : s2l) + nslot * kS2F, 0);   // (behind the last chunk: a slot nobody needs)
+        if (g + 1 < G) load_ops<LA, S2C>(nxt, s1l + slot * kS1F, s2l + slot2 * kS2F, (g + 1) * LA);
+        else           load_ops<LA, S2C>(nxt, s1l + nslot * kS1F, (K == NCH - 1 ? s2n : s2l) + nslot2 * kS2F, 0);   // (behind the last chunk: a slot nobody needs)
         __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the reads below the fmas they should overlap)
         if (!(PWC_PIPE_EXP & 1)) fma_ops<LA>(cur, st.acc2, st.acc1);
         __builtin_amdgcn_sched_barrier(0);
@@ -254,11 +260,11 @@ __device__ __forceinline__ void fma_step(FmaState<LA> &st, const PipeArgs &a, co
     asm volatile("" ::: "memory");
 }
 
-template <int NCH, int K, int LA, int S2C>
+template <int NCH, int K, int LA, int S2C, int S2R = kR>
 __device__ __forceinline__ void fma_steps(FmaState<LA> &st, const PipeArgs &a, const float *s1l, const float *s2l, const float *s2n, int wave, bool have_prev) {
     if constexpr (K < NCH) {
-        fma_step<NCH, K, LA, S2C>(st, a, s1l, s2l, s2n, wave, have_prev);
-        fma_steps<NCH, K + 1, LA, S2C>(st, a, s1l, s2l, s2n, wave, have_prev);
+        fma_step<NCH, K, LA, S2C, S2R>(st, a, s1l, s2l, s2n, wave, have_prev);
+        fma_steps<NCH, K + 1, LA, S2C, S2R>(st, a, s1l, s2l, s2n, wave, have_prev);
     }
 }
 
@@ -362,7 +368,7 @@ struct Loader {
         const pwc::v4i32 r1 = pwc::make_rsrc(ip1 + (int64_t)c0 * plane, nbytes);
         const pwc::v4i32 r2 = pwc::make_rsrc(ip2 + (int64_t)c0 * plane, nbytes);
         const unsigned b1 = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(s1ring + slot * kS1F));
-        const unsigned b2 = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(s2ring + slot * kS2F));
+        const unsigned b2 = (K1 > kS1I) ? (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(s2ring + slot * kS2F)) : 0u;
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
             if (k < kS1I) pwc::dma_b128(r1, b1 + k * 1024, off[k - K0]);
@@ -630,6 +636,385 @@ corr81_roll_kernel(PipeArgs a) {
 }
 
 // =====================================================================================================================
+// WARP: fused warp + correlation (PWCNet.py:212-213, 226-227, 240-241, 256-257: corr(c1, warp(c2, up_flow * s)); the warped tensor
+// has no other consumer).  The round-2 form had five waves gather the bilinear taps of the 640 halo pixels from global memory --
+// 640 eight-byte gather instructions per tile, 1.46 M per launch, which alone paced the kernel (profiles/r03_pmc_summary.txt).
+// Here the taps come out of LDS:
+//   * A SOURCE WINDOW of c2 -- 23 rows x 52 columns per channel, 4 channels per ring step -- is staged by 16-byte LDS-DMA like
+//     every other operand (19 coalesced instructions per chunk; neighbouring tiles' windows overlap, so most of it is an L2 hit,
+//     which the measurements of this round price at next to nothing).  Its origin follows the flow: the sample position of the
+//     tile's centre pixel, computed from one scalar load of the flow by every wave that needs it (loaders and producers run
+//     the same arithmetic on the same two numbers -- nothing is handed over).  The window leaves the halo tile a margin of
+//     4 columns / 3 rows of flow VARIATION inside the tile on every side (the flow itself may be anything).
+//   * Four PRODUCER waves own three halo pixels per lane: taps, weights and mask once per tile (pwc_warp_taps.h, the same code as
+//     every warp kernel), then per ring step two ds_read2_b32 + blend4 + one ds_write_b32 per pixel and channel into the in2 image
+//     the fma waves read, two steps ahead of them.
+//   * A pixel whose taps leave the window (wild flow, motion boundary) takes the round-2 path for that pixel only: 8-byte
+//     gathers from global memory, same blend -- bit-identical either way (test_warp_correlation_fused_equals_two_kernels).
+constexpr int kWR = 23, kWQ = 13, kWC = 4 * kWQ;              // window rows, 16-byte pieces per row, columns
+constexpr int kWMy = 3, kWMx = 4;                             // margins (rows / columns) around the halo tile's own extent
+constexpr int kWinF = kCK * kWR * kWC;                        // 4784 floats per ring slot
+constexpr int kWinI = (kCK * kWR * kWQ + 63) / 64;            // 19 LDS-DMA instructions per chunk (the last one partly out of range)
+constexpr int kWinSlots = 4, kS2Slots = 4;
+constexpr int kProducers = 4, kProdPx = 3;                    // 4 x 64 x 3 = 768 >= 640 halo pixels
+static_assert(kProducers * 64 * kProdPx >= kS2Rows * kPitch, "halo pixels");
+constexpr int kWaveWin0 = kND + 1, kWaveProd0 = kND + 3;      // waves: 0-8 fma, 9 in1 loader, 10-11 window loaders, 12-15 producers
+constexpr int kThreadsWarp = 64 * (kND + 3 + kProducers);     // 1024: four waves per SIMD, 128 registers
+constexpr int kLdsWarp = (kR * kS1F + kS2Slots * kS2F + kWinSlots * kWinF) * 4;
+static_assert(kLdsWarp <= 160 * 1024, "LDS");
+static_assert(kWR == kS2Rows + 2 * kWMy + 1 && kWC >= kPitch + 2 * kWMx + 1 + 3, "window covers the halo tile + margins + tap + alignment");
+
+__device__ __forceinline__ float scalar_load(const float *p) {      // wave-uniform address; not counted in vmcnt (the loaders count by hand)
+    float v;
+    asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+// window origin of a tile: from the sample position of its centre pixel (halo row 7, halo column 19), the same for every wave
+struct WinOrg { int wx0, wy0; };
+__device__ __forceinline__ WinOrg window_origin(const PipeArgs &a, const TileXY &t) {
+    const int gxc = min(t.x0 + 15, a.W - 1), gyc = min(t.y0 + 3, a.H - 1);
+    const float *fu = (const float *)pwc::uniform_ptr(a.flo + (int64_t)t.b * a.bsf + (int64_t)gyc * a.W + gxc);
+    const float u = scalar_load(fu) * a.flow_scale, v = scalar_load(fu + (int64_t)a.H * a.W) * a.flow_scale;
+    const float px = (float)gxc + u, py = (float)gyc + v;
+    const float gx = 2.0f * px / (float)max(a.W - 1, 1) - 1.0f, gy = 2.0f * py / (float)max(a.H - 1, 1) - 1.0f;
+    float ix, iy;
+    if (a.align_corners) { ix = (gx + 1.0f) / 2.0f * (float)(a.W - 1); iy = (gy + 1.0f) / 2.0f * (float)(a.H - 1); }
+    else                 { ix = ((gx + 1.0f) * (float)a.W - 1.0f) / 2.0f; iy = ((gy + 1.0f) * (float)a.H - 1.0f) / 2.0f; }
+    // anywhere is correct (pixels outside take the gather path); keep the integers small.  !(x > lo) also catches NaN
+    ix = !(ix > -64.0f) ? -64.0f : fminf(ix, (float)a.W + 64.0f);
+    iy = !(iy > -64.0f) ? -64.0f : fminf(iy, (float)a.H + 64.0f);
+    const int cx = (int)floorf(ix) - (gxc - t.x0 - 15), cy = (int)floorf(iy) - (gyc - t.y0 - 3);     // (undo the clamp of the centre pixel)
+    WinOrg o;
+    o.wx0 = (cx - 19 - kWMx) & ~3;            // 16-byte pieces: a multiple of 4 at or left of the leftmost tap (two's complement: floors)
+    o.wy0 = cy - 7 - kWMy;
+    return o;
+}
+
+// ---- window loader wave WHICH (0 / 1): instructions WHICH, WHICH + 2, ... of the chunk's 19 --------------------------------
+template <int WHICH>
+struct WinLoader {
+    static constexpr int I = (kWinI - WHICH + 1) / 2;       // 10 / 9
+    unsigned off[I];
+    const float *ip;
+    __device__ __forceinline__ void new_tile(const PipeArgs &a, int tile, int lane, int plane) {
+        const TileXY t = tile_of(tile, a.nblk, a.tiles_x, a.tiles_y);
+        const WinOrg o = window_origin(a, t);
+#pragma unroll
+        for (int j = 0; j < I; ++j) {
+            const int p = (WHICH + 2 * j) * 64 + lane;
+            const int c = p / (kWR * kWQ), rem = p % (kWR * kWQ), row = rem / kWQ, q = rem % kWQ;
+            const int iy = o.wy0 + row, ix = o.wx0 + 4 * q;
+            const bool ok = (c < kCK) && (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);       // W % 4 == 0: a piece is all-in or all-out
+            off[j] = ok ? (unsigned)(c * plane + iy * a.W + ix) * 4u : kOOBv;
+        }
+        ip = a.in2 + (int64_t)((PWC_PIPE_EXP & 32) ? 0 : t.b) * a.bs2;
+    }
+    __device__ __forceinline__ void issue(const PipeArgs &a, int chunk, int slot, float *win, int plane) {
+        const int c0 = chunk * kCK;
+        const int nbytes = min(kCK, a.C - c0) * plane * 4;        // channels past C fail the range check: zeros
+        const pwc::v4i32 rs = pwc::make_rsrc(ip + (int64_t)c0 * plane, nbytes);
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)pwc::lds_addr(win + slot * kWinF));
+#pragma unroll
+        for (int j = 0; j < I; ++j) pwc::dma_b128(rs, base + (WHICH + 2 * j) * 1024, off[j]);
+    }
+};
+
+// step s = t NCH + K: window chunk s+4 goes into the slot chunk s has left (the producers read chunk s two steps ago); then the
+// wave waits until chunk s+3 has landed (the barrier that ends the step promises it to the producers)
+template <int NCH, int K, int WHICH>
+__device__ __forceinline__ void win_loader_steps(WinLoader<WHICH> &ld, const PipeArgs &a, float *win, int lane, int plane, int t, int nsteps, int stride) {
+    if constexpr (K < NCH) {
+        constexpr int I = WinLoader<WHICH>::I;
+        const int s = t * NCH + K;
+        constexpr int kc = (K + kWinSlots) % NCH;
+        if (s + kWinSlots < nsteps && !(PWC_PIPE_EXP & 4)) {
+            if constexpr (kc == 0) ld.new_tile(a, (int)blockIdx.x + (t + (K + kWinSlots) / NCH) * stride, lane, plane);
+            ld.issue(a, kc, K % kWinSlots, win, plane);
+        }
+        if (s + kWinSlots < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(I) : "memory");      // chunk s+3 landed, chunk s+4 may fly
+        else                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        win_loader_steps<NCH, K + 1, WHICH>(ld, a, win, lane, plane, t, nsteps, stride);
+    }
+}
+
+template <int NCH, int WHICH>
+__device__ __forceinline__ void win_loader_wave(const PipeArgs &a, float *win, int lane, int my_tiles) {
+    constexpr int I = WinLoader<WHICH>::I;
+    __builtin_amdgcn_s_setprio(3);
+    const int plane = a.H * a.W, stride = gridDim.x, nsteps = my_tiles * NCH;
+    WinLoader<WHICH> ld;
+    ld.new_tile(a, blockIdx.x, lane, plane);
+#pragma unroll
+    for (int k = 0; k < kWinSlots; ++k) ld.issue(a, k, k, win, plane);      // chunks 0..3 of the first tile (NCH >= 8)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(I) : "memory");               // chunks 0, 1, 2 have landed
+    __builtin_amdgcn_s_barrier();                   // B_pre: the producers make the first two in2 chunks
+    __builtin_amdgcn_s_barrier();                   // B_0
+#pragma unroll 1
+    for (int t = 0; t < my_tiles; ++t) win_loader_steps<NCH, 0, WHICH>(ld, a, win, lane, plane, t, nsteps, stride);
+}
+
+// ---- in1 loader wave of the fused kernel: the ring form's loader restricted to in1 --------------------------------------
+template <int NCH, int K>
+__device__ __forceinline__ void in1_loader_steps(Loader<0, kS1I> &ld, const PipeArgs &a, float *s1ring, int lane, int plane, int t, int nsteps, int stride) {
+    if constexpr (K < NCH) {
+        const int s = t * NCH + K;
+        constexpr int kc = (K + kR - 1) % NCH;
+        if (s + kR - 1 < nsteps && !(PWC_PIPE_EXP & 4)) {
+            if constexpr (kc == 0) ld.new_tile(a, (int)blockIdx.x + (t + (K + kR - 1) / NCH) * stride, lane, plane);
+            ld.issue(a, kc, (K + kR - 1) % kR, s1ring, nullptr, plane);
+        }
+        if (s + kR - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kR - 3) * kS1I) : "memory");
+        else if (s + 1 < nsteps) wait_chunks_in_flight<kS1I>(max(nsteps - 1 - (s + 2), 0));
+        __builtin_amdgcn_s_barrier();
+        in1_loader_steps<NCH, K + 1>(ld, a, s1ring, lane, plane, t, nsteps, stride);
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void in1_loader_wave(const PipeArgs &a, float *s1ring, int lane, int my_tiles) {
+    __builtin_amdgcn_s_setprio(3);
+    const int plane = a.H * a.W, stride = gridDim.x, nsteps = my_tiles * NCH;
+    Loader<0, kS1I> ld;
+    ld.new_tile(a, blockIdx.x, lane, plane);
+#pragma unroll
+    for (int k = 0; k < kR - 1; ++k)
+        if (k < nsteps) ld.issue(a, k, k, s1ring, nullptr, plane);
+    wait_chunks_in_flight<kS1I>(max(min(kR - 1, nsteps) - 2, 0));     // chunks 0 and 1
+    __builtin_amdgcn_s_barrier();                   // B_pre
+    __builtin_amdgcn_s_barrier();                   // B_0
+#pragma unroll 1
+    for (int t = 0; t < my_tiles; ++t) in1_loader_steps<NCH, 0>(ld, a, s1ring, lane, plane, t, nsteps, stride);
+}
+
+// ---- producer waves ---------------------------------------------------------------------------------------------------
+struct ProdPx {                  // one halo pixel of this lane
+    int dst;                     // float index inside an in2 chunk image [c][16][40]; < 0: no pixel (slot past the 640)
+    int wt, wb;                  // float index of the top / bottom tap pair inside a window chunk image [c][23][52]; wt < 0: outside
+    int otop, obot;              // byte offsets of the pairs inside a plane (gather path)
+    float wa, wb_, wc, wd;
+};
+
+struct ProdFlow { float u[kProdPx], v[kProdPx]; WinOrg org; TileXY t; };      // what prod_setup needs from global memory, requested early
+
+// the flow at this lane's halo pixels and the window origin of `tile`: issued at the START of the last step of the tile before,
+// used at its end (a dependent global load behind a barrier would cost the producers ~1 us per tile)
+__device__ __forceinline__ void prod_fetch_flow(ProdFlow &pf, const PipeArgs &a, int tile, int pw, int lane) {
+    pf.t = tile_of(tile, a.nblk, a.tiles_x, a.tiles_y);
+    const int plane = a.H * a.W;
+    const float *fu = a.flo + (int64_t)pf.t.b * a.bsf;
+#pragma unroll
+    for (int k = 0; k < kProdPx; ++k) {
+        const int hp = (pw * kProdPx + k) * 64 + lane;              // consecutive lanes = consecutive halo columns
+        const int row = hp / kPitch, col = hp - row * kPitch;
+        const int gyc = min(max(pf.t.y0 - kD + row, 0), a.H - 1), gxc = min(max(pf.t.x0 - kD + col, 0), a.W - 1);
+        pf.u[k] = fu[(int64_t)gyc * a.W + gxc];
+        pf.v[k] = fu[(int64_t)plane + (int64_t)gyc * a.W + gxc];
+    }
+    pf.org = window_origin(a, pf.t);
+}
+
+__device__ __forceinline__ void prod_setup(ProdPx (&px)[kProdPx], const PipeArgs &a, const ProdFlow &pf, int pw, int lane) {
+#pragma unroll
+    for (int k = 0; k < kProdPx; ++k) {
+        const int hp = (pw * kProdPx + k) * 64 + lane;
+        const int row = hp / kPitch, col = hp - row * kPitch;
+        const int gy = pf.t.y0 - kD + row, gx = pf.t.x0 - kD + col;
+        const bool inimg = (gy >= 0) && (gy < a.H) && (gx >= 0) && (gx < a.W);
+        const float u = pf.u[k] * a.flow_scale, v = pf.v[k] * a.flow_scale;
+        const pwc_warp::PairTaps pt = pwc_warp::make_pair_taps((float)gx + u, (float)gy + v, a.H, a.W, a.align_corners, a.thr);
+        // a halo pixel outside the image is the correlation's zero padding: all four weights zero
+        px[k].wa = inimg ? pt.wa : 0.f; px[k].wb_ = inimg ? pt.wb : 0.f; px[k].wc = inimg ? pt.wc : 0.f; px[k].wd = inimg ? pt.wd : 0.f;
+        px[k].otop = pt.otop * 4;
+        px[k].obot = pt.obot * 4;
+        const int rt = pt.otop / a.W, xb = pt.otop - rt * a.W, rb = pt.obot / a.W;
+        const int wr = rt - pf.org.wy0, wr2 = rb - pf.org.wy0, wc = xb - pf.org.wx0;
+        const bool inside = (wr >= 0) && (wr2 < kWR) && (wr2 >= wr) && (wc >= 0) && (wc + 1 < kWC) && !(PWC_PIPE_EXP & 2048);
+        px[k].wt = inside ? wr * kWC + wc : -1;
+        px[k].wb = wr2 * kWC + wc;
+        px[k].dst = (hp < kS2Rows * kPitch) ? row * kPitch + col : -1;
+    }
+}
+
+struct ProdState {
+    ProdPx px[kProdPx];
+    const float *src;            // c2 of the tile's batch item
+    f32x2 gt[kProdPx][kCK], gb[kProdPx][kCK];     // taps of the pixels outside the window, gathered one step ahead
+};
+
+// pixels inside the window: two ds_read2_b32 + blend4 + one ds_write_b32 per pixel and channel.  (Requesting the reads of two or
+// three pixels before the first blend was tried: 16 / 32 more live registers next to the gathered taps spill at 128, 123 vs 109 us.)
+__device__ __forceinline__ void prod_sample(const ProdState &ps, float *dst, const float *win) {
+#pragma unroll
+    for (int k = 0; k < kProdPx; ++k) {
+        if (ps.px[k].dst >= 0 && ps.px[k].wt >= 0) {
+            f32x2 top[kCK], bot[kCK];
+#pragma unroll
+            for (int c = 0; c < kCK; ++c) {
+                const float *wt = win + c * kWR * kWC + ps.px[k].wt, *wb = win + c * kWR * kWC + ps.px[k].wb;
+                top[c] = (f32x2){wt[0], wt[1]};
+                bot[c] = (f32x2){wb[0], wb[1]};
+            }
+#pragma unroll
+            for (int c = 0; c < kCK; ++c)
+                dst[c * kS2Rows * kPitch + ps.px[k].dst] =
+                    pwc_warp::blend4(top[c][0], top[c][1], bot[c][0], bot[c][1], ps.px[k].wa, ps.px[k].wb_, ps.px[k].wc, ps.px[k].wd);
+        }
+    }
+}
+
+// pixels outside the window (wild flow, motion boundary): the round-2 path for those pixels only -- 8-byte gathers from global
+// memory, ISSUED one ring step before they are blended so that their round trip is behind a whole step of other work
+__device__ __forceinline__ void prod_gather_issue(ProdState &ps, const PipeArgs &a, int chunk) {
+    const int plane = a.H * a.W, c0 = chunk * kCK;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(pwc::uniform_ptr(ps.src + (int64_t)c0 * plane), 0,
+                                                                  __builtin_amdgcn_readfirstlane(min(kCK, a.C - c0) * plane * 4), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < kProdPx; ++k) {
+        const bool out = ps.px[k].dst >= 0 && ps.px[k].wt < 0;
+        if (__builtin_amdgcn_ballot_w64(out)) {                 // wave-uniform: some pixel of this slot has left the window
+            if (out) {
+#pragma unroll
+                for (int c = 0; c < kCK; ++c) {                 // channels past C fail the range check and read as 0 (ragged last chunk)
+                    ps.gt[k][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, ps.px[k].otop, c * plane * 4, 0));
+                    ps.gb[k][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, ps.px[k].obot, c * plane * 4, 0));
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void prod_gather_finish(const ProdState &ps, float *dst) {
+#pragma unroll
+    for (int k = 0; k < kProdPx; ++k) {
+        const bool out = ps.px[k].dst >= 0 && ps.px[k].wt < 0;
+        if (__builtin_amdgcn_ballot_w64(out)) {
+            if (out) {
+#pragma unroll
+                for (int c = 0; c < kCK; ++c)
+                    dst[c * kS2Rows * kPitch + ps.px[k].dst] = pwc_warp::blend4(ps.gt[k][c][0], ps.gt[k][c][1], ps.gb[k][c][0], ps.gb[k][c][1],
+                                                                                 ps.px[k].wa, ps.px[k].wb_, ps.px[k].wc, ps.px[k].wd);
+            }
+        }
+    }
+}
+
+// step s = t NCH + K: the in2 image of chunk s+2 from window chunk s+2, two steps ahead of the fma waves (they read one chunk ahead):
+// sample the pixels inside the window, finish the gathers issued during the previous step, then issue the gathers of chunk s+3 --
+// after moving on to the next tile's taps when chunk s+2 was the last of its tile (its flow was requested at the start of the step).
+template <int NCH, int K>
+__device__ __forceinline__ void prod_steps(ProdState &ps, const PipeArgs &a, float *s2ring, const float *win, int pw, int lane, int t, int nsteps, int stride) {
+    if constexpr (K < NCH) {
+        const int s = t * NCH + K;
+        constexpr int kc = (K + 2) % NCH;               // chunk (inside its tile) produced during this step
+        if (s + 2 < nsteps && !(PWC_PIPE_EXP & 4096)) {
+            ProdFlow pf;
+            const bool next_tile = (kc == NCH - 1) && (s + 3 < nsteps);
+            if constexpr (kc == NCH - 1)
+                if (next_tile) prod_fetch_flow(pf, a, (int)blockIdx.x + (t + (K + 3) / NCH) * stride, pw, lane);
+            float *dst = s2ring + ((K + 2) % kS2Slots) * kS2F;
+            prod_sample(ps, dst, win + ((K + 2) % kWinSlots) * kWinF);
+            prod_gather_finish(ps, dst);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is in LDS before this wave reaches the barrier
+            if (s + 3 < nsteps) {
+                if constexpr (kc == NCH - 1) {
+                    prod_setup(ps.px, a, pf, pw, lane);
+                    ps.src = a.in2 + (int64_t)((PWC_PIPE_EXP & 32) ? 0 : pf.t.b) * a.bs2;
+                }
+                prod_gather_issue(ps, a, (kc + 1) % NCH);
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        prod_steps<NCH, K + 1>(ps, a, s2ring, win, pw, lane, t, nsteps, stride);
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void producer_wave(const PipeArgs &a, float *s2ring, const float *win, int pw, int lane, int my_tiles) {
+    const int stride = gridDim.x, nsteps = my_tiles * NCH;
+    ProdState ps;
+    {
+        ProdFlow pf;
+        prod_fetch_flow(pf, a, blockIdx.x, pw, lane);
+        prod_setup(ps.px, a, pf, pw, lane);
+        ps.src = a.in2 + (int64_t)((PWC_PIPE_EXP & 32) ? 0 : pf.t.b) * a.bs2;
+    }
+    prod_gather_issue(ps, a, 0);
+    __builtin_amdgcn_s_barrier();                   // B_pre: window chunks 0, 1, 2 have landed
+    asm volatile("" ::: "memory");
+    prod_sample(ps, s2ring, win);
+    prod_gather_finish(ps, s2ring);
+    if (nsteps > 1) {
+        prod_gather_issue(ps, a, 1);
+        prod_sample(ps, s2ring + kS2F, win + kWinF);
+        prod_gather_finish(ps, s2ring + kS2F);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nsteps > 2) prod_gather_issue(ps, a, 2);    // (NCH >= 8: chunk 2 is in the first tile)
+    __builtin_amdgcn_s_barrier();                   // B_0
+    asm volatile("" ::: "memory");
+#pragma unroll 1
+    for (int t = 0; t < my_tiles; ++t) prod_steps<NCH, 0>(ps, a, s2ring, win, pw, lane, t, nsteps, stride);
+}
+
+template <int NCH>
+__device__ __forceinline__ void warp_fma_wave(const PipeArgs &a, const float *s1ring, const float *s2ring, int wave, int lane, int my_tiles) {
+    int r, g;
+    lane_to_rg(lane, r, g);
+    FmaState<1> st;
+#pragma unroll
+    for (int p = 0; p < kPX; ++p) {
+        st.acc1[p] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) st.acc2[p][m] = (f32x2){0.f, 0.f};
+    }
+#pragma unroll
+    for (int dx = 0; dx < kND; ++dx)
+#pragma unroll
+        for (int p = 0; p < kPX; ++p) st.done[dx][p] = 0.f;
+    st.plane4 = a.H * a.W * 4;
+    st.sbase = wave * kND * st.plane4;
+    st.voff = kOOBv;
+    st.rs = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
+    const int stride = gridDim.x;
+    const float *s1l = s1ring + r * kPitch + 4 * g, *s2l = s2ring + (r + wave) * kPitch + 4 * g;
+    __builtin_amdgcn_s_barrier();              // B_pre
+    __builtin_amdgcn_s_barrier();              // B_0: in1 chunks 0, 1 and the in2 images of chunks 0, 1 are readable
+    asm volatile("" ::: "memory");
+    load_ops<1, kS2Rows * kPitch>(st.ha, s1l, s2l, 0);
+#pragma unroll 1
+    for (int t = 0; t < my_tiles; ++t) {
+        if (t > 0) set_destination(st, a, (int)blockIdx.x + (t - 1) * stride, r, g);
+        fma_steps<NCH, 0, 1, kS2Rows * kPitch, kS2Slots>(st, a, s1l, s2l, s2l, wave, t > 0);
+    }
+    set_destination(st, a, (int)blockIdx.x + (my_tiles - 1) * stride, r, g);
+    tail_stores<NCH, 0, 1>(st, wave);
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(kThreadsWarp, 4)
+warp_corr81_pipe_kernel(PipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s1ring = smem;                            // [kR][kS1F]
+    float *s2ring = s1ring + kR * kS1F;              // [kS2Slots][kS2F]: produced
+    float *win = s2ring + kS2Slots * kS2F;           // [kWinSlots][kWinF]
+    static_assert(NCH % kR == 0 && NCH % kWinSlots == 0 && NCH % kS2Slots == 0, "static ring slots");
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int stride = gridDim.x;
+    const int my_tiles = (a.nblk - (int)blockIdx.x + stride - 1) / stride;
+    // barriers of every wave: B_pre, B_0 and one at the end of every ring step
+    if (wave == kND)                 in1_loader_wave<NCH>(a, s1ring, lane, my_tiles);
+    else if (wave == kWaveWin0)      win_loader_wave<NCH, 0>(a, win, lane, my_tiles);
+    else if (wave == kWaveWin0 + 1)  win_loader_wave<NCH, 1>(a, win, lane, my_tiles);
+    else if (wave >= kWaveProd0)     producer_wave<NCH>(a, s2ring, win, wave - kWaveProd0, lane, my_tiles);
+    else                             warp_fma_wave<NCH>(a, s1ring, s2ring, wave, lane, my_tiles);
+}
+
+// =====================================================================================================================
 template <int NCH>
 #ifdef PWC_PIPE_LOADERS4
 __global__ void __launch_bounds__(kThreadsPlain, 4)
@@ -661,7 +1046,7 @@ corr81_pipe_kernel(PipeArgs a) {
     else                             fma_wave<NCH, 2>(a, s1ring, s2ring, wave, lane, my_tiles);
 }
 
-pwc::LdsAttrOnce g_lds_plain8, g_lds_plain16, g_lds_roll;
+pwc::LdsAttrOnce g_lds_plain8, g_lds_plain16, g_lds_roll, g_lds_warp8, g_lds_warp16;
 
 }  // namespace
 
@@ -676,13 +1061,20 @@ bool corr81_pipe_fits(int B, int C, int H, int W) {
            (int64_t)H * W * 81 * 4 < 0x7fffffffLL;
 }
 
+// the fused window kernel: level 2 (C <= 32) by default -- at level 3 (448 tiles at batch 16: under two per workgroup) it only ties the
+// round-2 kernel, 49.6 vs 48.9 us; option "warpcorr_window" = 2 takes it there too
+bool warp_corr81_pipe_fits(int B, int C, int H, int W) {
+    const int nch = (C + kCK - 1) / kCK, mode = option(OPT_WARPCORR_WINDOW);
+    return mode > 0 && (nch == 8 || (nch == 16 && mode >= 2)) && W >= 2 && corr81_pipe_fits(B, C, H, W);
+}
+
 int launch_corr81_pipe(const float *in1, const float *in2, float *out, int B, int C, int H, int W,
                        int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky, hipStream_t st) {
     const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kTH - 1) / kTH;
     const int nblk = B * tiles_x * tiles_y;
     const int nch = (C + kCK - 1) / kCK;
     const int grid = nblk < 256 ? nblk : 256;       // one workgroup per CU (its LDS does not admit two)
-    PipeArgs a{in1, in2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0};
+    PipeArgs a{in1, in2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0, nullptr, 0, 0.f, 0.f, 0};
     if (nch == 8 && option(OPT_CORR_ROLL)) {
         // runs of seg_len tiles down a column: as long as possible while the runs still cover the chip about once
         int seg_len = nblk / 256;
@@ -707,6 +1099,27 @@ int launch_corr81_pipe(const float *in1, const float *in2, float *out, int B, in
         hipLaunchKernelGGL(corr81_pipe_kernel<16>, dim3((unsigned)grid), dim3(kThreadsPlain), kLdsPlain, st, a);
     }
     return check_launch("corr81_pipe_kernel");
+}
+
+int launch_warp_corr81_pipe(const float *in1, const float *x2, const float *flo, float *out, int B, int C, int H, int W,
+                            int64_t bs1, int64_t bs2, int64_t bsf, int64_t bso, float flow_scale, int align_corners, float thr,
+                            float scale, float slope, int do_leaky, hipStream_t st) {
+    const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kTH - 1) / kTH;
+    const int nblk = B * tiles_x * tiles_y;
+    const int nch = (C + kCK - 1) / kCK;
+    const int grid = nblk < 256 ? nblk : 256;
+    const PipeArgs a{in1, x2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0,
+                     flo, bsf, flow_scale, thr, align_corners};
+    if (nch == 8) {
+        int rc = ensure_lds_attr(g_lds_warp8, reinterpret_cast<const void *>(warp_corr81_pipe_kernel<8>), kLdsWarp, "warp_corr81_pipe_kernel<8>");
+        if (rc != PWC_OK) return rc;
+        hipLaunchKernelGGL(warp_corr81_pipe_kernel<8>, dim3((unsigned)grid), dim3(kThreadsWarp), kLdsWarp, st, a);
+    } else {
+        int rc = ensure_lds_attr(g_lds_warp16, reinterpret_cast<const void *>(warp_corr81_pipe_kernel<16>), kLdsWarp, "warp_corr81_pipe_kernel<16>");
+        if (rc != PWC_OK) return rc;
+        hipLaunchKernelGGL(warp_corr81_pipe_kernel<16>, dim3((unsigned)grid), dim3(kThreadsWarp), kLdsWarp, st, a);
+    }
+    return check_launch("warp_corr81_pipe_kernel");
 }
 
 }  // namespace pwc

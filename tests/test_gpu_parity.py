@@ -26,6 +26,63 @@ def dev(gpu_device):
 
 
 # ------------------------------------------------------------------ correlation
+
+@pytest.fixture
+def corr_options():
+    """flip the library's kernel-selection switches for one test and restore the defaults afterwards"""
+    from opticalflow_amd import _lib
+    names = ("corr_pipe", "corr_roll", "corr_pipe_min_tiles", "warpcorr_window")
+    saved = {n: _lib.get_option(n) for n in names}
+    yield _lib.set_option
+    for n, v in saved.items():
+        _lib.set_option(n, v)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 24, 64), (1, 64, 56, 128), (5, 32, 112, 256), (3, 29, 20, 44), (16, 32, 112, 256), (2, 61, 17, 36)])
+def test_corr_round4_kernels_bit_equal_round2_kernels(dev, corr_options, shape):
+    """The round-4 correlation kernels (pwc_corr_pipe.hip: one workgroup per CU, LDS-DMA ring / rolling in2 window, output leaving
+    plane by plane; fused form: warp taps sampled from an LDS window, gathers for the pixels that leave it) against the round-2
+    kernels on the same operands: bit-identical, also on ragged tiles, ragged channel chunks, arena-strided operands, runs of tiles
+    that wrap to a second segment, flows that leave the window and the image; NaN-filled outputs (an unwritten element must not pass)."""
+    from opticalflow_amd import ops
+    B, C, H, W = shape
+    c1 = seeded_rand(shape, 170, -1, 1).to(dev)
+    c2 = seeded_rand(shape, 171, -1, 1).to(dev)
+    flo = seeded_rand((B, 2, H, W), 172, -2, 2)
+    flo[0, :, : H // 3] *= 4.0                                        # part of image 0 samples far outside the window / the image
+    flo = flo.to(dev)
+    arena = torch.full((B, 81 + C + 2, H, W), 7.0, device=dev)
+    arena[:, 81:81 + C].copy_(c1)
+    corr_options("corr_pipe_min_tiles", 1)
+
+    def run(new, roll, fn):
+        corr_options("corr_pipe", new)
+        corr_options("corr_roll", roll)
+        corr_options("warpcorr_window", 2 * new)
+        out = torch.full((B, 81, H, W), float("nan"), device=dev)
+        assert fn(out) is not None
+        return out
+
+    for leaky, norm in ((None, False), (0.1, False), (0.1, True)):
+        fn = lambda out: ops.correlation(arena[:, 81:81 + C], c2, 4, 1, 4, 1, 1, 1.0, normalize=norm, leaky_slope=leaky, out=out)  # noqa: E731
+        old = run(0, 0, fn)
+        assert not torch.isnan(old).any()
+        assert torch.equal(old, run(1, 1, fn)), ("rolling / ring form", leaky, norm)
+        assert torch.equal(old, run(1, 0, fn)), ("ring form", leaky, norm)
+    for scale, align in ((5.0, False), (1.25, True)):
+        fn = lambda out: ops.warp_correlation(c1, c2, flo, flow_scale=scale, align_corners=align, leaky_slope=0.1, out=out)       # noqa: E731
+        old = run(0, 0, fn)
+        assert not torch.isnan(old).any()
+        assert torch.equal(old, run(1, 0, fn)), ("fused window form", scale, align)
+    assert (arena[:, 81:81 + C] == c1).all()
+
+
+def test_set_option_rejects_unknown_names(dev):
+    from opticalflow_amd import _lib
+    with pytest.raises(_lib.PwcHipError):
+        _lib.set_option("no_such_option", 1)
+    assert _lib.get_option("corr_pipe_min_tiles") >= 1
+
 def test_corr_golden_fast_and_scalar_paths(dev):
     from opticalflow_amd import ops
     g = load_golden("g1_corr.npz")

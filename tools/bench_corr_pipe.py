@@ -2,7 +2,7 @@
 """Round-4 correlation kernels (pwc_corr_pipe.hip) against the round-2 kernels they replace on the large levels: bit-equality
 on a set of shapes (ragged tiles, ragged channel chunks, arena-strided operands), then HIP-event timings at level 2 / 3 of the
 benchmark batch with three operand sets in rotation (> 256 MiB at level 2: nothing is served from the Infinity Cache).
-The two kernels are selected in ONE process through pwc_set_option("corr_pipe", 0/1).
+The kernels are selected in ONE process through pwc_set_option("corr_pipe" / "warpcorr_window").
 
 usage: python tools/bench_corr_pipe.py [check|time|all] [smooth|noise]"""
 import os
@@ -33,6 +33,7 @@ def both(fn, shape_out):
     res = []
     for on in (0, 1):
         _lib.set_option("corr_pipe", on)
+        _lib.set_option("warpcorr_window", 2 * on)
         out = torch.full(shape_out, float("nan"), device=dev)
         r = fn(out)
         res.append(None if r is None else out)
@@ -96,21 +97,47 @@ def t(fns, reps=30):
     return s.elapsed_time(e) / reps * 1e3
 
 
+def plan_operands():
+    """c1 / c2 / up_flow of decoder levels 2 and 3 as the benchmark's forward leaves them (synthetic weights of bench.py)"""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    net = PWCDCNet()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
+    net = net.to(dev).eval()
+    x = torch.rand(B, 6, 448, 1024, generator=torch.Generator().manual_seed(1234)).to(dev)
+    net(x)
+    plan = net._plan_for(x)
+    out = {}
+    for lvl, C in ((2, 32), (3, 64)):
+        ar = plan.arena[lvl]
+        off = plan.arena_base[lvl] + 81 if hasattr(plan, "arena_base") else 448 + 81
+        out[lvl] = (ar[:, off:off + C].clone(), plan.c2[lvl].clone(), ar[:, off + C:off + C + 2].clone())
+    return out
+
+
 def timing():
     levels = [int(v) for v in os.environ.get("PWC_BENCH_LEVELS", "2,3").split(",")]
+    po = plan_operands() if flow_kind == "plan" else None
     for lvl, C, H, W, scale in ((2, 32, 112, 256, 5.0), (3, 64, 56, 128, 2.5), (4, 96, 28, 64, 1.25), (5, 128, 14, 32, 0.625)):
         if lvl not in levels:
             continue
         sets = []
         for _ in range(3):
-            c1 = torch.randn(B, C, H, W, generator=g).to(dev)
-            c2 = torch.randn(B, C, H, W, generator=g).to(dev)
-            flo = make_flow(B, H, W, 0.6 if flow_kind == "smooth" else 0.4)
+            if po is not None and lvl in po:
+                c1, c2, flo = (v.clone() for v in po[lvl])
+                if _ == 0:
+                    print("level %d plan flow: mean |f| %.2f px, mean |df/dx| %.2f" % (lvl, (flo * scale).abs().mean().item(),
+                          ((flo[..., 1:] - flo[..., :-1]) * scale).abs().mean().item()), flush=True)
+            else:
+                c1 = torch.randn(B, C, H, W, generator=g).to(dev)
+                c2 = torch.randn(B, C, H, W, generator=g).to(dev)
+                flo = make_flow(B, H, W, 0.6 if flow_kind == "smooth" else 0.4)
             sets.append((c1, c2, flo, torch.empty(B, 81, H, W, device=dev)))
         _lib.set_option("corr_pipe_min_tiles", 1)
         res = {}
         for name, on in (("old", 0), ("new", 1), ("old", 0), ("new", 1)):
             _lib.set_option("corr_pipe", on)
+            _lib.set_option("warpcorr_window", 2 * on)
             plain = t([(lambda s=s: ops.correlation(s[0], s[1], 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1, out=s[3])) for s in sets])
             fused = t([(lambda s=s: ops.warp_correlation(s[0], s[1], s[2], flow_scale=scale, leaky_slope=0.1, out=s[3])) for s in sets])
             res.setdefault(name, []).append((plain, fused))
