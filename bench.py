@@ -375,13 +375,15 @@ def main():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--conv-backend", default="hip", choices=["hip", "torch"])
     ap.add_argument("--precision", default=None, choices=["fp32", "fp16", "fp16-strict"],
-                    help="fp32 = the headline metric (BASELINE configs[2]); fp16 = half activations/filters, fp32 accumulation (configs[3])")
+                    help="fp32 = the headline metric (BASELINE configs[2]); fp16-strict = the half-precision mode that meets the 1e-3 tolerance "
+                         "(default of --workload kitti); fp16 = half activations/filters everywhere, fp32 accumulation (configs[3], misses it)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
     if args.precision is None:
-        args.precision = "fp16" if args.workload == "kitti" else "fp32"
+        # configs[4] names fp16; the half-precision mode that meets north_star's tolerance is the strict one (the fast mode: --precision fp16)
+        args.precision = "fp16-strict" if args.workload == "kitti" else "fp32"
     if args.batch is None:
         args.batch = 16
 
@@ -532,48 +534,33 @@ def main():
                 ref0 = O.pwc_forward(sd_cpu, x[:1].cpu())
             result["epe_vs_cpu_oracle_headline_item0"] = float("%.3e" % O.epe(net(x)[:1].cpu(), ref0))
         if world == 1 and fp32 and args.conv_backend == "hip" and not args.no_graph:
-            # side measurement, not the metric: the same workload through the half-precision plan (BASELINE configs[3]
-            # per-GPU shard), timed the same way after the fp32 region; `python bench.py --precision fp16` is the full line
-            log("side measurement: same workload, precision=fp16")
-            net16 = PWCDCNet(use_graph=True, precision="fp16").to(dev).eval()
-            net16.load_state_dict(net.state_dict())
-            x16 = net16.graph_input(B, H, W, dev)
-            x16.copy_(x)
-            for _ in range(3):
-                net16(x16)
-            torch.cuda.synchronize()
-            t16 = time.perf_counter()
-            for _ in range(args.steps):
-                out16 = net16(x16)
-            torch.cuda.synchronize()
-            dt16 = time.perf_counter() - t16
-            f32out = net(x)
-            result["fp16_same_workload"] = {
-                "value": round(B * args.steps / dt16, 3), "unit": "image-pairs/s", "ms_per_step": round(1e3 * dt16 / args.steps, 4),
-                "dtype": "f16 activations/filters, f32 accumulation",
-                "epe_vs_fp32_plan": float("%.3e" % O.epe(out16.cpu(), f32out.cpu())),
-                "mean_abs_flow": float("%.3e" % f32out.abs().mean().item())}
-            del net16
-            # ... and through the STRICT half-precision mode (pyramid / levels 6..3 / warps in fp32, level 2 + context network in half
-            # with split filters): the variant that meets north_star's 1e-3 mean EPE
-            log("side measurement: same workload, precision=fp16-strict")
-            nets = PWCDCNet(use_graph=True, precision="fp16-strict").to(dev).eval()
-            nets.load_state_dict(net.state_dict())
-            xs_ = nets.graph_input(B, H, W, dev)
-            xs_.copy_(x)
-            for _ in range(3):
-                nets(xs_)
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(args.steps):
-                outs_ = nets(xs_)
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - ts
-            result["fp16_strict_same_workload"] = {
-                "value": round(B * args.steps / dts, 3), "unit": "image-pairs/s", "ms_per_step": round(1e3 * dts / args.steps, 4),
-                "dtype": "f32 pyramid / levels 6-3 / warps; f16 activations with split (hi+lo) filters at level 2 and in the context network",
-                "epe_vs_fp32_plan": float("%.3e" % O.epe(outs_.cpu(), f32out.cpu()))}
-            del nets
+            # side measurements, not the metric: the same workload (BASELINE configs[3]'s per-GPU shard) through the two half-precision
+            # plans, timed the same way after the fp32 region.  The STRICT mode first: it is the one that meets north_star's 1e-3 mean
+            # EPE (fp32 pyramid / levels 6-3 / warps, level 2 + context network in half with split filters); the fast mode
+            # (half everywhere, ~1.2e-3 x mean |flow|) does not.  `python bench.py --precision fp16-strict | fp16` give full lines.
+            f32out = net(x).clone()
+            for prec, key, dtype in (("fp16-strict", "fp16_strict_same_workload",
+                                      "f32 pyramid / levels 6-3 / warps; f16 activations with split (hi+lo) filters at level 2 and in the context network"),
+                                     ("fp16", "fp16_same_workload", "f16 activations/filters, f32 accumulation")):
+                log("side measurement: same workload, precision=%s" % prec)
+                neth = PWCDCNet(use_graph=True, precision=prec).to(dev).eval()
+                neth.load_state_dict(net.state_dict())
+                xh = neth.graph_input(B, H, W, dev)
+                xh.copy_(x)
+                for _ in range(3):
+                    neth(xh)
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                for _ in range(args.steps):
+                    outh = neth(xh)
+                torch.cuda.synchronize()
+                dth = time.perf_counter() - th
+                result[key] = {
+                    "value": round(B * args.steps / dth, 3), "unit": "image-pairs/s", "ms_per_step": round(1e3 * dth / args.steps, 4),
+                    "dtype": dtype, "meets_1e-3_mean_epe": prec == "fp16-strict",
+                    "epe_vs_fp32_plan": float("%.3e" % O.epe(outh.cpu(), f32out.cpu())),
+                    "mean_abs_flow": float("%.3e" % f32out.abs().mean().item())}
+                del neth, xh
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
             torch.set_num_threads(cores)

@@ -573,6 +573,38 @@ def test_forward_fp16_strict_meets_north_star(dev):
     assert ek < 1e-3
 
 
+STRICT_REL_BAR = 0.75e-3       # mean EPE / mean |flow2| of the strict mode: measured 0.50-0.60e-3 (printed by the tests)
+
+
+@pytest.mark.parametrize("gain", [0.88, 0.90])
+def test_forward_fp16_strict_larger_motion(dev, gain):
+    """Where the strict mode's 1e-3 stops holding.  Its error is RELATIVE to the flow magnitude -- the rounding of
+    the stored level-2 / context activations -- so north_star's absolute 1e-3 is met while mean |flow2| stays below ~1.8.  The same
+    weights at a higher gain give mean |flow2| 2.5 (gain 0.88) and 4.0 (0.90) on a 256x512 pair: the test reports EPE absolute AND
+    relative against the CPU oracle, asserts the relative bound (and that the mode still beats the fast one by the usual factor),
+    and documents that the absolute figure exceeds 1e-3 there.  Statement of the range: INTEGRATION.md section 4."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    from oracle import pwc_oracle as O
+    net = PWCDCNet(precision="fp16-strict").to(dev).eval()
+    fast = PWCDCNet(precision="fp16").to(dev).eval()
+    sd = synthetic_state_dict(net.manifest(), seed=0, gain=gain, bias_std=0.02)
+    net.load_state_dict(sd)
+    fast.load_state_dict(sd)
+    x = torch.rand(1, 6, 256, 512, generator=torch.Generator().manual_seed(1234))
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = O.pwc_forward(sd, x)
+    mag = ref.abs().mean().item()
+    e = O.epe(net(x.to(dev)).cpu(), ref)
+    ef = O.epe(fast(x.to(dev)).cpu(), ref)
+    print("fp16-strict, gain %.2f: mean|flow2| %.2f, EPE %.3e absolute = %.3e x mean|flow2| (fast mode %.3e = %.3e x)"
+          % (gain, mag, e, e / mag, ef, ef / mag))
+    assert 2.0 < mag < 6.0                      # the input does have the larger motion the test is about
+    assert e < STRICT_REL_BAR * mag
+    assert e < 0.75 * ef
+
+
 def test_forward_fp16_strict_full_size_batch16(dev):
     """16 x 6 x 448 x 1024 (BASELINE configs[3]'s per-GPU shard) in the strict mode: items 0 and 15 against the CPU oracle under
     the 1e-3 bar, bit-repeatable run to run, 16 copies of one pair give 16 identical flows."""

@@ -1024,6 +1024,73 @@ def test_conv3x3_winograd4_vs_fp64(gpu_device, case):
     assert (lin.double() - F.conv2d(x.double(), w.double(), b.double(), padding=1)).abs().max().item() <= 1e-6 * (cin * 9) ** 0.5
 
 
+def _wino4_rel_errors(gpu_device, x, w, b):
+    """max over outputs of |kernel - fp64| / S, S = sum |x||w| + |b| of that output, for F(4x4), F(2x2) and the direct kernel"""
+    from opticalflow_amd import ops
+    cout = w.shape[0]
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    S = F.conv2d(x.double().abs(), w.double().abs(), None, padding=1) + b.double().abs().view(1, -1, 1, 1)
+    xd, wd, bd = x.to(gpu_device), w.to(gpu_device), b.to(gpu_device)
+    outs = (ops.conv3x3_wino4(xd, ops.pack_conv3x3_wino4(wd), bd, cout, leaky_slope=None),
+            ops.conv3x3_wino(xd, ops.pack_conv3x3_wino(wd), bd, cout, leaky_slope=None),
+            ops.conv3x3(xd, ops.pack_conv3x3(wd), bd, cout, leaky_slope=None))
+    return [((o.cpu().double() - ref).abs() / S).max().item() for o in outs]
+
+
+WINO4_REL_BAR = 2.0e-6        # |err| <= 2e-6 x sum|x||w| per output: ~33 ulp of fp32 on a 5 085-term sum (measured <= 1.2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["offset", "relu_like", "heavy_tail"])
+def test_conv3x3_winograd4_robust_to_offsets_and_outliers(gpu_device, kind):
+    """F(4,3)'s error scales with max |x||w| per tile, not with the rms of the result, and the other F(4x4) tests
+    feed zero-mean unit gaussians.  dc_conv1's channel counts (565 -> 128) on (i) x = 8 + randn, a map with a large common-mode offset,
+    (ii) a post-LeakyReLU-like positive map, (iii) a gaussian map with 0.1 % of its entries x 50.  Bound: per output relative to
+    S = sum |x||w| against fp64 (WINO4_REL_BAR), and no more than 5x the larger of F(2x2)'s figure and the direct kernel's -- measured
+    (profiles/r04_wino4_robustness.txt): F(4x4) 1.1e-7 / 2.9e-7 / 1.2e-6, F(2x2) 0.7e-7 / 1.0e-7 / 2.8e-7, direct 1.8e-7 / 2.0e-7 / 5.9e-7:
+    no guard (mean subtraction) is needed, the rebalanced interpolation points keep F(4x4) within 2x of the direct fp32 kernel."""
+    cin, cout, H, W = 565, 128, 32, 64
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(1, cin, H, W, generator=g)
+    if kind == "offset":
+        x = x + 8.0
+    elif kind == "relu_like":
+        x = x.abs() * 3 + 2
+    else:
+        x[torch.rand(x.shape, generator=g) < 1e-3] *= 50.0
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    e4, e2, ed = _wino4_rel_errors(gpu_device, x, w, b)
+    print("F(4x4) robustness [%s]: max |err| / sum|x||w| = %.2e (F(2x2) %.2e, direct %.2e)" % (kind, e4, e2, ed))
+    assert e4 <= WINO4_REL_BAR
+    assert e4 <= 5.0 * max(e2, ed)
+
+
+@pytest.mark.gpu
+def test_conv3x3_winograd4_on_the_plans_own_level2_arena(gpu_device):
+    """... and (iv) the real thing: the level-2 arena a forward of the benchmark network leaves behind (565 channels: four LeakyReLU'd
+    dense-block outputs, the LeakyReLU'd cost volume, c1, up_flow, up_feat -- very different scales per channel group) through dc_conv1's
+    own filters by F(4x4), 32 rows of it against fp64."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    net = PWCDCNet().to(gpu_device).eval()
+    sd = synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02)
+    net.load_state_dict(sd)
+    xin = torch.rand(1, 6, 448, 1024, generator=torch.Generator().manual_seed(1234)).to(gpu_device)
+    net(xin)
+    plan = net._plan_for(xin)
+    arena = plan.arena[2][:, :565, 40:72].contiguous().cpu()                   # [1, 565, 32, 256] as dc_conv1 reads it
+    groups = {"dense": arena[:, :448], "corr": arena[:, 448:529], "c1": arena[:, 529:561], "flow": arena[:, 561:565]}
+    print("level-2 arena: " + ", ".join("%s mean|x| %.3f max %.1f" % (k, v.abs().mean().item(), v.abs().max().item()) for k, v in groups.items()))
+    w, b = sd["dc_conv1.0.weight"], sd["dc_conv1.0.bias"]
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    e4, e2, ed = _wino4_rel_errors(gpu_device, arena, w, b)
+    print("F(4x4) on the plan's level-2 arena: max |err| / sum|x||w| = %.2e (F(2x2) %.2e, direct %.2e)" % (e4, e2, ed))
+    assert e4 <= WINO4_REL_BAR
+    assert e4 <= 5.0 * max(e2, ed)
+
+
 @pytest.mark.gpu
 def test_conv3x3_winograd4_arena_views_rule_and_errors(gpu_device):
     """Channel-slice views of a wider arena on both sides, as the decoder uses them; the measured rule; unsupported geometry is an
