@@ -378,6 +378,7 @@ def main():
                     help="fp32 = the headline metric (BASELINE configs[2]); fp16-strict = the half-precision mode that meets the 1e-3 tolerance "
                          "(default of --workload kitti); fp16 = half activations/filters everywhere, fp32 accumulation (configs[3], misses it)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's flow gather before the next forward (round-3 behaviour, for A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -397,7 +398,7 @@ def main():
 
     import torch.distributed as dist
     from opticalflow_amd import PWCDCNet, _lib
-    from opticalflow_amd.parallel import broadcast_parameters, gather_flows
+    from opticalflow_amd.parallel import AsyncFlowGather, broadcast_parameters
     from opticalflow_amd.weights import synthetic_state_dict
 
     _lib.load()                                   # no HIP library -> no benchmark
@@ -433,11 +434,14 @@ def main():
         xin.copy_(x)
         x = xin
     counts = [B] * world
+    # N > 1: the flows of step k travel to rank 0 on a side stream while forward k+1 runs (parallel.AsyncFlowGather); the timed region
+    # ends with a synchronize of that stream, so every gather is inside it
+    gather = AsyncFlowGather(counts, (2, H // 4, W // 4), torch.float32, dev, dst=0) if world > 1 else None
 
     def step():
         flow = net(x)
         if world > 1:
-            return gather_flows(flow, counts, dst=0)
+            return gather.result(gather.submit(flow)) if args.sync_gather else gather.submit(flow)
         return flow
 
     log("rank %d/%d: net on %s, batch %d x 6x%dx%d resident; warm-up x%d" % (rank, world, dev, B, H, W, args.warmup))
@@ -453,6 +457,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if world > 1:
+        gather.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -534,7 +534,7 @@ conv3x3_wino4p_kernel(const float *__restrict__ x, const float *__restrict__ up,
 __global__ void __launch_bounds__(256)
 wino4_tail_reduce_kernel(const float *__restrict__ ws, const float *__restrict__ bias, float *__restrict__ y, int ksplit, int per_image, int pos0,
                          int ntail, int tiles_x, int th, int tw, int H, int W, int Cout, int co0, int ncout, int64_t bsy, float slope,
-                         int do_leaky, int64_t total) {
+                         int do_leaky, int split2, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int q4 = tw >> 2;
@@ -558,7 +558,13 @@ wino4_tail_reduce_kernel(const float *__restrict__ ws, const float *__restrict__
         v[i] += bv;
         if (do_leaky) v[i] = leaky(v[i], slope);
     }
-    *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + ((int64_t)co * H + oy) * W + ox) = v;
+    if (!split2) {
+        *reinterpret_cast<f32x4 *>(y + (int64_t)b * bsy + ((int64_t)co * H + oy) * W + ox) = v;
+    } else {            // PWC_CONV_SPLIT2: image b as its four pixel lattices (the main kernel's epilogue does the same)
+        float *d0 = y + ((int64_t)b * 4 + 2 * (oy & 1)) * bsy + (int64_t)co * (((int64_t)H * W) >> 2) + (int64_t)(oy >> 1) * (W >> 1) + (ox >> 1);
+        *reinterpret_cast<f32x2 *>(d0) = (f32x2){v[0], v[2]};
+        *reinterpret_cast<f32x2 *>(d0 + bsy) = (f32x2){v[1], v[3]};
+    }
 }
 
 // Inverse of L nested PWC_CONV_SPLIT2 stores (see pwc_hip.h): one thread per four output pixels of a row; the four come from four
@@ -591,22 +597,61 @@ inline int cout_padded4(int Cout) { return (Cout + 31) / 32 * 32; }
 // chip idle: 896 workgroups (the 64-cout layers of level 2) = 3.5 rounds cost 4, 448 = 1.75 cost 2 -- 12.5 % of those layers.  When the
 // last round is partial (and at least one full round precedes it) its tiles go into a second launch that cuts every tile into
 // two slices of the input channels, so that the slices fill the chip (128 tiles x 2 = 256 half-length workgroups); a small third
-// kernel adds the slices in a fixed order.  Option "w4_tailsplit" = 0 (pwc_set_option / PWC_W4_TAILSPLIT) switches it off.
-constexpr int kCUs = 256;
+// kernel adds the slices in a fixed order.  Option "w4_tailsplit" = 0 (pwc_set_option / PWC_W4_TAILSPLIT) switches it off;
+// "w4_smallsplit" = 0 the whole-launch form for launches smaller than the chip.
+constexpr int kCUsDefault = 256;
+// CUs of the current device (cached per device; 256 on MI355X in SPX mode -- a partitioned device reports fewer and the plans follow)
+inline int device_cus() {
+    static std::atomic<int> cached[pwc::kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= pwc::kMaxDevices) return kCUsDefault;
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = kCUsDefault;
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
 struct TailPlan { int main_tiles, ksplit, cps; int64_t ws_bytes; };
+
+// A workgroup costs ~10 us outside its K loop = the time of ~3.3 four-channel chunks (dc_conv1: 3 us per chunk and round)
+constexpr double kFixedChunks = 3.3;
+// SMALL launches (batches 1-4: script_pwc.py and inference_kitti.py run one pair): fewer workgroups than CUs.  Every tile is cut into
+// ksplit slices of the input channels so that tiles x cout groups x slices cover the chip once; ksplit minimises
+// rounds x (chunks per slice + fixed cost), at least 6 chunks per slice, at most 8 slices.
+inline int wino4_small_ksplit(int64_t nwg, int nchunks, int cus) {
+    int best = 1;
+    double best_cost = (double)((nwg + cus - 1) / cus) * (nchunks + kFixedChunks);
+    for (int k = 2; k <= 8 && nchunks / k >= 6; ++k) {
+        const double cost = (double)((nwg * k + cus - 1) / cus) * ((nchunks + k - 1) / k + kFixedChunks) + 0.5 * k;      // + the reduce kernel's reads
+        if (cost < 0.9 * best_cost) { best = k; best_cost = cost; }
+    }
+    return best;
+}
 
 // The tail is made of the same (last) tile positions of EVERY image, so the result of an item does not depend on its slot in the batch.
 inline TailPlan wino4_tail_plan(int B, int64_t nblk, int ngroups, int nchunks, int Cout, int tile_px, int split2) {
     TailPlan p{(int)nblk, 1, nchunks, 0};
-    const int knob = pwc::option(pwc::OPT_W4_TAILSPLIT);
-    const int64_t nwg = nblk * ngroups, full = nwg / kCUs, rem = nwg - full * kCUs;
-    if (!knob || split2 || full < 1 || rem == 0 || (kCUs % ngroups) != 0) return p;
-    const int64_t main_tiles = full * kCUs / ngroups, tail = nblk - main_tiles;
+    const int cus = device_cus();
+    const int64_t nwg = nblk * ngroups, full = nwg / cus, rem = nwg - full * cus;
+    if (full < 1) {
+        // whole-launch split (main_tiles = 0): every tile of every image alike, so an item's result does not depend on its slot either
+        if (!pwc::option(pwc::OPT_W4_SMALLSPLIT)) return p;
+        const int k = wino4_small_ksplit(nwg, nchunks, cus);
+        if (k == 1) return p;
+        p.main_tiles = 0;
+        p.ksplit = k;
+        p.cps = (nchunks + k - 1) / k;
+        p.ws_bytes = (int64_t)k * nblk * Cout * tile_px * (int64_t)sizeof(float);
+        return p;
+    }
+    if (!pwc::option(pwc::OPT_W4_TAILSPLIT) || split2 || rem == 0 || (cus % ngroups) != 0) return p;
+    const int64_t main_tiles = full * cus / ngroups, tail = nblk - main_tiles;
     if ((main_tiles & 7) || (tail & 7) || (tail % B)) return p;  // keep the XCD-aware tile order of both launches; whole positions
-    // Two slices, and only when they fit ONE half-length round (rem <= 128 workgroups): a slice costs ~10 us outside its K loop, so four
+    // Two slices, and only when they fit ONE half-length round (rem <= half the CUs): a slice costs ~10 us outside its K loop, so four
     // quarter-length slices per tile measured no gain (448 workgroups = 1.75 rounds: 297 us unsplit, 314 us as 256 + 768 quarter slices),
     // while 896 = 3 rounds + 256 half slices gains 7-10 % (conv2_3 728 -> 668 us, the 64-cout launch of conv2_2 580 -> 542 us).
-    const int best = (nchunks / 2 >= 12 && rem * 2 <= kCUs) ? 2 : 1;
+    const int best = (nchunks / 2 >= 12 && rem * 2 <= cus) ? 2 : 1;
     if (best == 1) return p;
     p.main_tiles = (int)main_tiles;
     p.ksplit = best;
@@ -631,9 +676,10 @@ int launch_wino4(const float *x, const float *up, const float *bias, float *y, i
     if (nblk * ngroups > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv3x3_wino4_fwd: grid too large");
     TailPlan tp = wino4_tail_plan(B, nblk, ngroups, (Cin + kCK - 1) / kCK, Cout, kTH * GW, split2);
     if (tp.ksplit > 1 && (!workspace || workspace_bytes < tp.ws_bytes || (reinterpret_cast<uintptr_t>(workspace) & 15u))) tp = TailPlan{(int)nblk, 1, 0, 0};
-    hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG, GW>), dim3((unsigned)(tp.main_tiles * ngroups)), dim3(kThreads), kSmemP, st,
-                       x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, tp.main_tiles, ngroups, split2,
-                       TailSplit{tp.main_tiles / B, 0, 1, 0, nullptr});
+    if (tp.main_tiles > 0)
+        hipLaunchKernelGGL((conv3x3_wino4p_kernel<CB, TG, GW>), dim3((unsigned)(tp.main_tiles * ngroups)), dim3(kThreads), kSmemP, st,
+                           x, up, bias, y, Cin, H, W, Cout, CoutP, tiles_x, tiles_y, bsx, bsy, slope, do_leaky, co0, tp.main_tiles, ngroups, split2,
+                           TailSplit{tp.main_tiles / B, 0, 1, 0, nullptr});
     if (tp.ksplit > 1) {
         const int ntail = (int)nblk - tp.main_tiles;
         float *ws = static_cast<float *>(workspace);
@@ -643,7 +689,7 @@ int launch_wino4(const float *x, const float *up, const float *bias, float *y, i
         const int ncout = min(ngroups * G::kCoutT, Cout - co0);
         const int64_t total = (int64_t)ntail * ncout * kTH * (GW / 4);
         hipLaunchKernelGGL(wino4_tail_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           ws, bias, y, tp.ksplit, ntail / B, tp.main_tiles / B, ntail, tiles_x, kTH, GW, H, W, Cout, co0, ncout, bsy, slope, do_leaky, total);
+                           ws, bias, y, tp.ksplit, ntail / B, tp.main_tiles / B, ntail, tiles_x, kTH, GW, H, W, Cout, co0, ncout, bsy, slope, do_leaky, split2, total);
     }
     pwc::note_kernel("conv3x3_wino4p_kernel", CB, TG, GW, tp.ksplit, 1, 0);
     return pwc::check_launch("conv3x3_wino4p_kernel");
@@ -674,15 +720,25 @@ extern "C" int pwc_conv3x3_wino4_preferred(int B, int Cin, int H, int W, int Cou
     const int n32 = cout_padded4(Cout) / 32;
     const int gw = wino4_gw(W), gh = gw == 64 ? 4 : 8;                 // a tile group is gh rows x gw columns
     const int tiles_x = (W + gw - 1) / gw;
+    const int nchunks = (Cin + kCK - 1) / kCK;
     // every launch the layer splits into must cover the chip: the 64-cout launch (two tile groups per workgroup) and, for an odd number
-    // of 32-cout blocks, the 32-cout one (four groups) -- conv3_2 (96 couts @56x128) fails on the latter (128 workgroups, x0.94)
+    // of 32-cout blocks, the 32-cout one (four groups) -- conv3_2 (96 couts @56x128) fails on the latter (128 workgroups, x0.94).  A launch
+    // smaller than the chip counts with the input-channel slices wino4_tail_plan cuts it into (small batches), provided a slice keeps
+    // a K loop worth its fixed cost.
+    auto covers = [&](int64_t nblk, int ngroups) {
+        const int64_t nwg = nblk * ngroups;
+        if (nwg >= 200) return true;
+        if (!pwc::option(pwc::OPT_W4_SMALLSPLIT)) return false;
+        const int k = wino4_small_ksplit(nwg, nchunks, device_cus());
+        return nwg * k >= 160 && nchunks / k >= 6;
+    };
     if (n32 >= 2) {
         const int th = 2 * gh;
-        if (wino4_row_fill(H, th) < 0.85 || (int64_t)B * tiles_x * ((H + th - 1) / th) * (n32 / 2) < 200) return 0;
+        if (wino4_row_fill(H, th) < 0.85 || !covers((int64_t)B * tiles_x * ((H + th - 1) / th), n32 / 2)) return 0;
     }
     if (n32 & 1) {
         const int th = 4 * gh;
-        if (wino4_row_fill(H, th) < 0.85 || (int64_t)B * tiles_x * ((H + th - 1) / th) < 200) return 0;
+        if (wino4_row_fill(H, th) < 0.85 || !covers((int64_t)B * tiles_x * ((H + th - 1) / th), 1)) return 0;
     }
     return (double)W / (tiles_x * gw) >= 0.85;
 }
@@ -740,7 +796,7 @@ extern "C" int pwc_conv3x3_wino4_fwd(const void *x, const void *up, const void *
     return PWC_OK;
 }
 
-// Scratch for the tail split of launch_wino4 (0: this layer's launches have no partial last round worth splitting)
+// Scratch for the tail / whole-launch split of launch_wino4 (0: neither applies to this layer's launches)
 extern "C" int64_t pwc_conv3x3_wino4_workspace_bytes(int B, int Cin, int H, int W, int Cout) {
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || !wino4_supported(W, 1)) return 0;
     const int n32 = cout_padded4(Cout) / 32, nchunks = (Cin + kCK - 1) / kCK;

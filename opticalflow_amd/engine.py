@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 
 PYRAMID_CH = (3, 16, 32, 64, 96, 128, 196)
 PYRAMID_NAMES = (("conv1a", "conv1aa", "conv1b"), ("conv2a", "conv2aa", "conv2b"), ("conv3a", "conv3aa", "conv3b"),
@@ -135,7 +135,8 @@ class PwcPlan:
         # images of half the size, with contiguous rows: F(4x4) / F(2x2) at their dilation-1 speed instead of strided lattice
         # addressing (dc_conv2 611 -> ~430 us, dc_conv3 679 -> ~470 us at batch 16).  dc_conv5 (dilation 16) is a dilation-2
         # convolution on the dilation-8 lattices; its 64-channel result is brought back to NCHW by pwc_lattice_unsplit_f32.
-        wino_on = os.environ.get("PWC_CONV_WINO", "1") != "0" and os.environ.get("PWC_CONV_WINO4", "1") != "0"
+        wino_on = (os.environ.get("PWC_CONV_WINO", "1") != "0" and os.environ.get("PWC_CONV_WINO4", "1") != "0"
+                   and (conv_backend != "hip" or _lib.get_option("conv_wino4") != 0))
         self.ctx_lattice = bool(
             trunk2 and conv_backend == "hip" and dtype == torch.float32 and wino_on and os.environ.get("PWC_CTX_LATTICE", "1") != "0"
             and h2 % 8 == 0 and w2 % 32 == 0
@@ -155,7 +156,8 @@ class PwcPlan:
         self.split96_bias: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.conv_macs = {"direct": 0, "executed": 0}
         self.wino = os.environ.get("PWC_CONV_WINO", "1") != "0" and dtype == torch.float32
-        self.wino4 = os.environ.get("PWC_CONV_WINO4", "1") != "0"          # 0: large layers stay on F(2x2,3x3) (A/B runs, error budget)
+        # 0 (environment, or pwc_set_option("conv_wino4", 0) before the plan is built): large layers stay on F(2x2,3x3) (A/B runs, error budget)
+        self.wino4 = os.environ.get("PWC_CONV_WINO4", "1") != "0" and (conv_backend != "hip" or _lib.get_option("conv_wino4") != 0)
         self.workspace: Optional[torch.Tensor] = None
         if conv_backend == "hip":
             for key, t in self.p.items():
@@ -200,29 +202,52 @@ class PwcPlan:
                         self.wino4_packed[key] = ops.pack_conv3x3_wino4(self.p[key + ".weight"])
                     elif key in self.wino_packed and self._split96_wanted(b_, cin, h, w, co):
                         self._pack_split96(key)
-            # one split-K scratch shared by every stride-1 conv of the decoder (they run back to back on one stream)
-            need = 0
-            for l in range(2 if trunk2 else 3, 7):
-                h, w = self.size[l]
-                cin = level_in_channels(l, self.nd)
-                for co in DENSE_OUT + (2,):
-                    need = max(need, ops.conv3x3_workspace_bytes(B, cin, h, w, co))
-                    if self.wino and co >= 32:
-                        need = max(need, ops.conv3x3_wino_workspace_bytes(B, cin, h, w, co))
-                        if self.wino4:                                  # tail split of the F(4x4) launches (and of the 64-cout part of a 96-cout layer)
-                            need = max(need, ops.conv3x3_wino4_workspace_bytes(B, cin, h, w, co), ops.conv3x3_wino4_workspace_bytes(B, cin, h, w, min(co, 64)))
-                    cin += co if co != 2 else 0
-            # the context layers can split too (dilated: D*D lattices; at small batch / image sizes they fall into the split-K
-            # window) -- pwc_conv3x3_wino_preferred counts the split, so the workspace must be there for it
-            h, w = self.size[2]
-            cin = level_in_channels(2, self.nd) + DENSE_TOTAL
-            for co, dil in (CONTEXT if trunk2 else ()):
-                need = max(need, ops.conv3x3_workspace_bytes(B, cin, h, w, co, 1, dil))
-                if self.wino and dil <= 8:
-                    need = max(need, ops.conv3x3_wino_workspace_bytes(B, cin, h, w, co, dil))
-                cin = co
+            # ONE scratch shared by every convolution of the plan (they run back to back on one stream): split-K of the direct and
+            # F(2x2) kernels, tail / whole-launch split of F(4x4).  pwc_conv3x3_wino*_preferred count those splits, so the buffer has to
+            # cover EVERY launch the plan can make -- decoder, pyramid (2B images), context layers in NCHW and in the lattice-major
+            # layout (the lattice geometries and the pyramid were missing; the C side then quietly ran unsplit).
+            self.workspace_need = self._workspace_bytes(B, trunk2)
+            need = self.workspace_need
             if need:
                 self.workspace = torch.empty((need // 4,), **kw)
+
+    def _launch_geometries(self, B: int, trunk2: bool):
+        """(images, cin, h, w, cout, dilation) of every 3x3 stride-1 convolution this plan can launch"""
+        out = []
+        for l in range(1, 7):                                  # pyramid: the stride-1 layers of each level on both images
+            h, w = self.size[l]
+            for n in self.pyramid_names[l - 1][1:]:
+                if n is not None:
+                    out.append((self._slots(B), PYRAMID_CH[l], h, w, PYRAMID_CH[l], 1))
+        for l in range(2 if trunk2 else 3, 7):                 # dense blocks + flow heads
+            h, w = self.size[l]
+            cin = level_in_channels(l, self.nd)
+            for co in DENSE_OUT + (2,):
+                out.append((B, cin, h, w, co, 1))
+                out.append((B, cin, h, w, min(co, 64), 1))     # the F(4x4) part of a 96-cout layer run as 64 + 32
+                cin += co if co != 2 else 0
+        if trunk2:
+            h, w = self.size[2]
+            cin = level_in_channels(2, self.nd) + DENSE_TOTAL
+            for co, dil in CONTEXT:
+                out.append((B, cin, h, w, co, dil))
+                cin = co
+            if getattr(self, "ctx_lattice", False):            # the same layers on their pixel lattices (see __init__)
+                c = [co for co, _ in CONTEXT]
+                out += [(4 * B, c[0], h // 2, w // 2, c[1], 1), (16 * B, c[1], h // 4, w // 4, c[2], 1),
+                        (64 * B, c[2], h // 8, w // 8, c[3], 1), (64 * B, c[2], h // 8, w // 8, 64, 1), (64 * B, c[2], h // 8, w // 8, 32, 1),
+                        (64 * B, c[3], h // 8, w // 8, c[4], 2)]
+        return out
+
+    def _workspace_bytes(self, B: int, trunk2: bool) -> int:
+        need = 0
+        for n, cin, h, w, co, dil in self._launch_geometries(B, trunk2):
+            need = max(need, ops.conv3x3_workspace_bytes(n, cin, h, w, co, 1, dil))
+            if self.wino and co >= 32 and dil <= 8:
+                need = max(need, ops.conv3x3_wino_workspace_bytes(n, cin, h, w, co, dil))
+            if self.wino and self.wino4 and co >= 32 and dil == 1 and w % 4 == 0:
+                need = max(need, ops.conv3x3_wino4_workspace_bytes(n, cin, h, w, co))
+        return need
 
     @staticmethod
     def _slots(B: int) -> int:
@@ -422,7 +447,7 @@ class PwcPlan:
             macs = x.shape[0] * w.shape[0] * w.shape[1] * 9 * x.shape[2] * x.shape[3]
             self.conv_macs["direct"] += macs
             self.conv_macs["executed"] += macs * 36 // 144
-            ops.conv3x3_wino4(x, self.wino4_packed[key], b, w.shape[0], leaky_slope=LEAKY, out=out, split2=split2)
+            ops.conv3x3_wino4(x, self.wino4_packed[key], b, w.shape[0], leaky_slope=LEAKY, out=out, split2=split2, workspace=self.workspace)
 
         w4("dc_conv1", self.arena[2], self.ctx[0], True)          # [B,565,H,W]      -> 4B  x [128,H/2,W/2]   (lattices of dilation 2)
         w4("dc_conv2", self.ctx[0], self.ctx[1], True)            # dilation 2 = 1 on those -> 16B x [128,H/4,W/4]

@@ -97,6 +97,63 @@ class FlowGather:
         return self.out
 
 
+class AsyncFlowGather:
+    """FlowGather off the compute stream: step k's flows are gathered while forward k+1 runs.
+
+    bench.py's N > 1 loop used to enqueue the gather to rank 0 behind each forward on the compute stream, so forward k+1 waited for
+    gather k (26 MB into rank 0 at N = 8, an estimated 0.2-0.3 ms of a 10.7 ms step).  Here the flows of step k are copied into one of
+    two staging buffers on a SIDE stream (which waits for an event recorded behind forward k), the collective is issued on that
+    stream (RCCL orders itself after the stream that is current when it is called), and an event marks its end; the compute stream
+    never waits for any of it.  ``submit`` returns at once; ``result(k)`` gives step k's gathered tensor on ``dst`` (None elsewhere)
+    after making the CALLER's stream wait for its event -- valid until the submit two steps later reuses the buffers.  With a CPU
+    / gloo group there are no streams and the call degenerates to the synchronous gather: same results, which is what the
+    world-size-2 test pins; the overlap itself is checked on the GPU with event timestamps (tests/test_gpu_rccl.py)."""
+
+    def __init__(self, counts: List[int], tail: Tuple[int, ...], dtype: torch.dtype, device: torch.device, dst: int = 0, group=None):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.rank = dist.get_rank(group)
+        self.dst = dst
+        self.count = counts[self.rank]
+        # two independent gathers: their receive buffers are the double buffer of the results
+        self.g = [FlowGather(counts, tail, dtype, device, dst, group) for _ in range(2)]
+        self.stage = [torch.empty((self.count,) + tuple(tail), dtype=dtype, device=self.device) for _ in range(2)] if self.cuda else None
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.ready = [torch.cuda.Event() for _ in range(2)] if self.cuda else None          # recorded behind the forward
+        self.done = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.cuda else None   # recorded behind the gather
+        self.out = [None, None]
+        self.k = 0
+
+    def submit(self, local: torch.Tensor) -> int:
+        """enqueue the gather of this step's flows; returns the step number to pass to result()"""
+        k, i = self.k, self.k & 1
+        self.k += 1
+        if not self.cuda:
+            self.out[i] = self.g[i](local)
+            return k
+        cur = torch.cuda.current_stream(self.device)
+        self.ready[i].record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ready[i])
+            self.stage[i].copy_(local, non_blocking=True)        # the caller may overwrite / free `local` once its own stream moves on
+            local.record_stream(self.side)
+            self.out[i] = self.g[i](self.stage[i])
+            self.done[i].record(self.side)
+        return k
+
+    def result(self, k: int) -> Optional[torch.Tensor]:
+        if k < self.k - 2 or k >= self.k:
+            raise ValueError("step %d is not one of the two most recent submits (%d submitted)" % (k, self.k))
+        i = k & 1
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.done[i])
+        return self.out[i]
+
+    def synchronize(self) -> None:
+        if self.cuda:
+            self.side.synchronize()
+
+
 _GATHERS = {}
 
 

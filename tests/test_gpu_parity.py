@@ -1193,6 +1193,89 @@ def test_conv3x3_winograd4_tail_split_vs_fp64(gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 565, 128, 112, 256, False), (1, 469, 64, 112, 256, False), (2, 533, 32, 112, 256, False),
+                                  (1, 565, 128, 112, 256, True), (4, 128, 128, 56, 128, True)])
+def test_conv3x3_winograd4_small_batch_whole_launch_split(gpu_device, case):
+    """Small batches (script_pwc.py and inference_kitti.py run ONE pair): an F(4x4) launch with fewer workgroups than CUs is cut along
+    Cin into ksplit slices per tile -- tiles x cout groups x slices cover the chip once -- and wino4_tail_reduce_kernel adds the slices
+    in a fixed order (the same machinery as the partial-last-round split, main launch empty).  dc_conv1 at batch 1
+    (112 workgroups -> 2 slices), conv2_3 (56 -> 4), conv2_4 at batch 2 (56 -> 4), and the PWC_CONV_SPLIT2 (lattice) store of the context
+    network through the reduce kernel: against fp64 under the F(4x4) budget, against the unsplit launch (summation order only),
+    bit-repeatable, independent of the batch slot, and the rule now takes these layers."""
+    from opticalflow_amd import ops, _lib
+    B, cin, cout, H, W, split2 = case
+    need = ops.conv3x3_wino4_workspace_bytes(B, cin, H, W, cout)
+    assert need > 0 and ops.conv3x3_wino4_preferred(B, cin, H, W, cout)
+    _lib.set_option("w4_smallsplit", 0)
+    try:
+        assert ops.conv3x3_wino4_workspace_bytes(B, cin, H, W, cout) == 0 and not ops.conv3x3_wino4_preferred(B, cin, H, W, cout)
+    finally:
+        _lib.set_option("w4_smallsplit", 1)
+    ws = torch.empty(need // 4, device=gpu_device)
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xd, up, bd = x.to(gpu_device), ops.pack_conv3x3_wino4(w.to(gpu_device)), b.to(gpu_device)
+    got = ops.conv3x3_wino4(xd, up, bd, cout, workspace=ws, split2=split2)
+    kern = _lib.load().pwc_last_conv_kernel().decode()
+    assert "wino4p" in kern and kern.split(",")[3].strip() != "1", kern           # <CB, TG, GW, ksplit, ...>: it did split
+    assert torch.equal(ops.conv3x3_wino4(xd, up, bd, cout, workspace=ws, split2=split2), got)
+    plain = ops.conv3x3_wino4(xd, up, bd, cout, split2=split2)                 # no workspace: the unsplit launch
+    d = (plain - got).abs().max().item()
+    assert 0 < d <= 8.1e-5
+    nat = ops.lattice_unsplit(got, B, 1) if split2 else got                     # back to NCHW for the comparison
+    torch.set_num_threads(max(8, torch.get_num_threads()))
+    ref = F.leaky_relu(F.conv2d(x[:1].double(), w.double(), b.double(), padding=1), 0.1)
+    err = (nat[:1].cpu().double() - ref).abs().max().item()
+    print("small-batch split %s: %s max err %.2e (budget %.2e), split vs unsplit %.2e" % (case, kern, err, 1e-6 * (cin * 9) ** 0.5, d))
+    assert err <= 1e-6 * (cin * 9) ** 0.5
+    if B > 1:
+        same = xd[:1].expand(B, -1, -1, -1).contiguous()
+        r = ops.conv3x3_wino4(same, up, bd, cout, workspace=ws, split2=split2)
+        n = r.shape[0] // B
+        assert all(torch.equal(r[:n], r[i * n:(i + 1) * n]) for i in range(1, B))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 4])
+def test_plan_workspace_covers_every_launch(gpu_device, monkeypatch, B):
+    """the plan's shared scratch must cover the split-K / tail / whole-launch split of EVERY convolution it launches (the C side
+    falls back to the unsplit launch when the buffer is too small -- correct, and slow without anyone noticing).  Every conv call of one
+    forward is recorded and its workspace demand compared with what the plan holds; at these batch sizes the lattice-major context
+    network and the F(4x4) route with input-channel slices are in use."""
+    from opticalflow_amd import PWCDCNet, ops
+    from opticalflow_amd.weights import synthetic_state_dict
+    net = PWCDCNet().to(gpu_device).eval()
+    net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
+    x = torch.rand(B, 6, 448, 1024, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    ref = net(x).clone()
+    plan = net._plan_for(x)
+    have = plan.workspace.numel() * 4 if plan.workspace is not None else 0
+    calls = []
+    real = {n: getattr(ops, n) for n in ("conv3x3", "conv3x3_wino", "conv3x3_wino4")}
+
+    def spy(name):
+        def f(xx, wp, bias, cout, *a, **kw):
+            dil = kw.get("dilation", 1)
+            n, cin, h, w = xx.shape
+            fn = {"conv3x3": lambda: ops.conv3x3_workspace_bytes(n, cin, h, w, cout, kw.get("stride", 1), dil),
+                  "conv3x3_wino": lambda: ops.conv3x3_wino_workspace_bytes(n, cin, h, w, cout, dil),
+                  "conv3x3_wino4": lambda: ops.conv3x3_wino4_workspace_bytes(n, cin, h, w, cout)}[name]
+            calls.append((name, (n, cin, h, w, cout, dil), fn(), kw.get("workspace") is not None))
+            return real[name](xx, wp, bias, cout, *a, **kw)
+        return f
+    for n in real:
+        monkeypatch.setattr(ops, n, spy(n))
+    out = plan.run(x) if hasattr(plan, "run") else net(x)
+    assert torch.equal(out, ref)
+    assert len(calls) > 40 and any(c[0] == "conv3x3_wino4" for c in calls)
+    short = [c for c in calls if c[2] > have or (c[2] > 0 and not c[3])]
+    assert not short, short
+    assert getattr(plan, "ctx_lattice", False), "lattice-major context network expected at batch %d" % B
+
+
+@pytest.mark.gpu
 def test_forward_winograd4_error_budget(gpu_device, monkeypatch):
     """Whole-forward gate of the F(4x4) route on the benchmark workload, 16 x 6 x 448 x 1024 -- where the rule sends
     twelve level-2 / level-3 / pyramid / context layers to F(4x4): EPE of items 0 and 15 against the CPU oracle below 1e-4, the whole

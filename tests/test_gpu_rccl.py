@@ -20,7 +20,7 @@ import torch.distributed as dist
 sys.path.insert(0, %(root)r)
 from opticalflow_amd import PWCDCNet, _lib
 from opticalflow_amd.kitti import ShardedStream, evaluate_pairs_sharded
-from opticalflow_amd.parallel import FlowGather, ShardedFlow, broadcast_parameters, gather_flows
+from opticalflow_amd.parallel import AsyncFlowGather, FlowGather, ShardedFlow, broadcast_parameters, gather_flows
 from opticalflow_amd.weights import synthetic_state_dict
 
 _lib.load()
@@ -47,6 +47,33 @@ fg = FlowGather([2], (2, 16, 32), torch.float32, dev)
 assert torch.equal(fg(flow[:2]), flow[:2])
 sf = ShardedFlow(lambda t: net(t).clone())
 assert torch.equal(sf(3, lambda a, b: x[a:b]), flow)
+
+# overlapped gather (bench.py N > 1): same tensors as the synchronous form, and -- by event timestamps on this one GPU -- forward k+1
+# STARTS before gather k has finished.  A one-rank gather is a copy of a few KB, so the side stream is slowed down artificially
+# (a spin kernel in front of the collective) to make the order observable; the synchronous form could never show it.
+net.use_graph = True
+xg = net.graph_input(3, 64, 128, dev)
+xg.copy_(x)
+ag = AsyncFlowGather([3], (2, 16, 32), torch.float32, dev)
+starts = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+flows, tickets = [], []
+for k in range(4):
+    starts[k].record()
+    f = net(xg)
+    flows.append(f.clone())
+    with torch.cuda.stream(ag.side):
+        torch.cuda._sleep(20_000_000)                      # ~10 ms of spinning ahead of gather k on the side stream
+    tickets.append(ag.submit(f))
+    if k >= 1:
+        got = ag.result(tickets[k - 1])                    # waits (on the current stream) for gather k-1 only
+        assert got is not None and torch.equal(got, flows[k - 1]) and torch.equal(got, flow)
+ag.synchronize()
+torch.cuda.synchronize()
+assert torch.equal(ag.result(tickets[3]), flows[3])
+lead = starts[2].elapsed_time(ag.done[1])                  # gather 1 finished this many ms AFTER forward 2 was enqueued to start
+assert lead > 0.0, lead
+print("overlap: gather 1 finished %.2f ms after forward 2 started" % lead)
+net.use_graph = False
 
 dist.barrier()
 t = torch.tensor([1.25], device=dev, dtype=torch.float64)

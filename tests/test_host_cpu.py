@@ -68,9 +68,19 @@ def test_abi_argument_errors_without_gpu():
     assert lib.pwc_conv3x3_wino4_packed_bytes(5, 7) == 2 * 36 * 4 * 32 * 4
     p4 = lib.pwc_conv3x3_wino4_preferred
     assert p4(16, 565, 112, 256, 128, 1) == 1 and p4(16, 373, 112, 256, 96, 1) == 1 and p4(64, 128, 56, 128, 128, 1) == 1
-    assert p4(16, 405, 56, 128, 96, 1) == 0          # its 32-cout launch would have 128 workgroups
     assert p4(16, 128, 112, 256, 128, 2) == 0        # dilated layers: F(2x2) on lattices, or the lattice-major layout (engine)
-    assert p4(1, 565, 112, 256, 128, 1) == 0         # batch 1 does not fill the chip
+    # launches smaller than the chip count with the input-channel slices the launcher cuts them into (round 4, option "w4_smallsplit"):
+    # conv3_2's 32-cout launch (128 workgroups -> 2 slices) and dc_conv1 at batch 1 (112 workgroups -> 2 slices) are taken ...
+    assert p4(16, 405, 56, 128, 96, 1) == 1 and p4(1, 565, 112, 256, 128, 1) == 1
+    assert lib.pwc_conv3x3_wino4_workspace_bytes(1, 565, 112, 256, 128) == 2 * 56 * 128 * 8 * 64 * 4      # 2 slices x 56 tiles x 128 couts x 8x64 pixels
+    assert p4(1, 64, 14, 32, 64, 1) == 0              # ... a launch whose slices would be shorter than 6 chunks is not
+    assert lib.pwc_set_option(b"w4_smallsplit", 0) == 0
+    try:                                              # option off: the round-3 rule
+        assert p4(16, 405, 56, 128, 96, 1) == 0 and p4(1, 565, 112, 256, 128, 1) == 0
+        assert lib.pwc_conv3x3_wino4_workspace_bytes(1, 565, 112, 256, 128) == 0
+    finally:
+        assert lib.pwc_set_option(b"w4_smallsplit", 1) == 0
+    assert lib.pwc_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.pwc_last_error()
     assert p4(1024, 128, 14, 32, 64, 1) == 1         # narrow maps: 2 x 8 tile groups
     assert p4(16, 16, 224, 512, 16, 1) == 0 and p4(16, 64, 112, 254, 64, 1) == 0
     vp = ctypes.c_void_p

@@ -52,6 +52,26 @@ def _worker(rank, world, port, nitems, ok):
             assert out is not None and torch.equal(out, _fake_flow(full))
         else:
             assert out is None
+        # the overlapped form (bench.py's N > 1 loop): submit() per step, result(k) of the two most recent steps -- on a CPU group it
+        # degenerates to the synchronous gather and must give the same tensors, step after step, ragged counts included
+        from opticalflow_amd.parallel import AsyncFlowGather, shard_range
+        spans = [shard_range(nitems, world, r) for r in range(world)]
+        counts = [b - a for a, b in spans]
+        ag = AsyncFlowGather(counts, (2, 4, 8), torch.float32, torch.device("cpu"))
+        tickets = []
+        for step in range(4):
+            xs = torch.rand(nitems, 6, 16, 32, generator=torch.Generator().manual_seed(50 + step))
+            a, b = spans[rank]
+            tickets.append((ag.submit(_fake_flow(xs[a:b])), _fake_flow(xs)))
+            if step >= 1:                                  # read the PREVIOUS step's result after the next submit: double buffering
+                k, want = tickets[step - 1]
+                got = ag.result(k)
+                assert (got is None) if rank else torch.equal(got, want)
+        try:
+            ag.result(0)
+            raise AssertionError("a result older than two submits must be refused")
+        except ValueError:
+            pass
         # wrong bookkeeping is rejected
         try:
             gather_flows(torch.zeros(1, 2, 4, 8), [2] * world)
