@@ -72,7 +72,7 @@ torch.cuda.synchronize()
 assert torch.equal(ag.result(tickets[3]), flows[3])
 lead = starts[2].elapsed_time(ag.done[1])                  # gather 1 finished this many ms AFTER forward 2 was enqueued to start
 assert lead > 0.0, lead
-print("overlap: gather 1 finished %.2f ms after forward 2 started" % lead)
+print("overlap: gather 1 finished %%.2f ms after forward 2 started" %% lead)
 net.use_graph = False
 
 dist.barrier()
