@@ -351,15 +351,26 @@ def self_launch(n):
     has).  The child's stdout is ours -- rank 0's single JSON line passes through -- and its exit code becomes ours."""
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log("--gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)))
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
-    sys.exit(subprocess.call(cmd, env=env))
+    rc = 1
+    for attempt in range(2):        # a port found by bind-and-close can be taken before torchrun binds it: one retry with a new one (ADVICE r3)
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("--gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)))
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        out, _ = proc.communicate()
+        rc = proc.returncode
+        if out:
+            sys.stdout.write(out)
+            sys.stdout.flush()
+        if rc == 0 or out.strip():  # success, or a rank got far enough to print: not a rendezvous failure
+            break
+        log("launch failed before any rank printed (rc %d)%s" % (rc, ": retrying with another port" if attempt == 0 else ""))
+    sys.exit(rc)
 
 
 def main():

@@ -69,7 +69,12 @@ image_conv_s2_f32_kernel(const float *__restrict__ x, const float *__restrict__ 
         const float *p = tile + (2 * row) * kInW + 2 * col;
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 7; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], p[koff[s]], c, 0, 0, 0);
+        for (int s = 0; s < 7; ++s) {
+            // K is padded from 27 to 28: the pad step multiplies an explicit zero, not a real image value by a zero filter -- 0 x Inf would
+            // put a NaN into an output whose 3x3 window does not contain the non-finite pixel
+            const float bval = (4 * s + kq < 27) ? p[koff[s]] : 0.f;
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bval, c, 0, 0, 0);
+        }
         acc[g] = c;
     }
     // ---- bias, LeakyReLU, stores: D rows = couts 4 kq .. 4 kq + 3, column = pixel n (64 contiguous bytes per cout and group)

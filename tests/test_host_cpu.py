@@ -345,16 +345,26 @@ def test_bench_self_launches_its_ranks(monkeypatch):
     import bench
     seen = {}
 
-    def fake_call(cmd, env=None):
-        seen["cmd"], seen["env"] = cmd, env
-        return 7
+    class FakeProc:
+        """first launch: dies before any rank prints (a rendezvous failure: the port was taken) -> ONE retry with a new port;
+        second launch: a rank printed, exit code 7 is passed on"""
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen.setdefault("cmds", []).append(cmd)
+            seen["cmd"], seen["env"] = cmd, env
+            self.returncode = 1 if len(seen["cmds"]) == 1 else 7
 
-    monkeypatch.setattr(subprocess, "call", fake_call)
+        def communicate(self):
+            return ("" if len(seen["cmds"]) == 1 else '{"metric": "x"}\n'), None
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--workload", "kitti"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     with pytest.raises(SystemExit) as ei:
         bench.main()
-    assert ei.value.code == 7
+    assert ei.value.code == 7 and len(seen["cmds"]) == 2
+    a, b = seen["cmds"]
+    ip = a.index("--master-port") + 1
+    assert a[:ip] + a[ip + 1:] == b[:ip] + b[ip + 1:]           # the same command; the port may differ
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
