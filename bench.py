@@ -33,6 +33,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_CEILING_GBS = 6290.0
+HBM_CORR_MIX_CEILING_GBS = 5030.0    # streaming float4 kernel moving the correlation's 116 MB in + 150 MB out, cold, 16 384 WGs, nt stores (profiles/r04_corr_notes.md section 1)
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md: ~2.5 PF)
 GAIN, BIAS_STD = 0.85, 0.02    # synthetic-weight recipe shared with tests/golden (mean |flow2| ~ 1)
@@ -85,7 +86,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PWC_BENCH_CPU_THREADS", "16"))))
 
 
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
 
 
 def pmc_record(key, applies):
@@ -184,9 +185,12 @@ def probes_fp32(result, args, plan, B, H, W, h2, w2, stream):
     ms = event_time_ms([(lambda m=m, f=f: ops.warp_correlation(m[:, 81:81 + c2], f, m[:, 81 + c2:], flow_scale=5.0, leaky_slope=0.1,
                                                                out=m[:, :81])) for m, f, _ in sets], PROBE_REPS, stream)
     gbs = bytes_fused / (ms * 1e-3) / 1e9
-    rec = pmc_record("warp_corr81_level2_b16", full)
-    result["roofline_corr"] = {"kernel": "corr81_dma_kernel<warp> = warp + 81-channel correlation + LeakyReLU fused (level 2: C=32 @%dx%d, B=%d, "
-                                         "arena-strided operands; 3 operand sets in rotation)" % (w2, h2, B),
+    from opticalflow_amd import _lib
+    window = _lib.get_option("warpcorr_window") > 0      # the round-4 source-window kernel (default) or the round-2 gather kernel
+    rec = pmc_record("warp_corr81_level2_b16" if window else "warp_corr81_round2_level2_b16", full)
+    result["roofline_corr"] = {"kernel": "%s = warp + 81-channel correlation + LeakyReLU fused (level 2: C=32 @%dx%d, B=%d, arena-strided operands, "
+                                         "the forward's own up_flow; 3 operand sets in rotation)"
+                                         % ("warp_corr81_pipe_kernel<8>" if window else "corr81_dma_kernel<true>", w2, h2, B),
                                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(gbs / HBM_COPY_CEILING_GBS, 4),
                                "traffic": rec.get("traffic"), "traffic_source": rec.get("traffic_source"),
@@ -197,11 +201,13 @@ def probes_fp32(result, args, plan, B, H, W, h2, w2, stream):
     bytes_corr = (2 * c2 + 81) * h2 * w2 * 4 * B
     ms_c = event_time_ms([(lambda m=m, w_=w_: ops.correlation(m[:, 81:81 + c2], w_, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1, out=m[:, :81]))
                           for m, _, w_ in sets], PROBE_REPS, stream)
-    rec = pmc_record("corr81_level2_b16", full)
-    result["roofline_corr_plain"] = {"kernel": "corr81_dma_kernel (correlation alone, same operands)", "bound": "hbm",
+    rolled = _lib.get_option("corr_pipe") > 0
+    rec = pmc_record("corr81_roll_level2_b16" if rolled else "corr81_level2_b16", full)
+    result["roofline_corr_plain"] = {"kernel": "%s (correlation alone, same operands)" % ("corr81_roll_kernel" if rolled else "corr81_dma_kernel<false>"), "bound": "hbm",
                                      "achieved": round(bytes_corr / (ms_c * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(bytes_corr / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": rec.get("traffic"),
                                      "traffic_source": rec.get("traffic_source"), "avg_launch_ms": round(ms_c, 4),
+                                     "frac_of_mixed_stream_ceiling": round(bytes_corr / (ms_c * 1e-3) / 1e9 / HBM_CORR_MIX_CEILING_GBS, 4),
                                      "launches_timed": PROBE_REPS, "algorithmic_bytes_per_launch": bytes_corr}
     if args.conv_backend != "hip":
         result["roofline"] = result["roofline_corr"]

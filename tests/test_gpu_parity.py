@@ -534,6 +534,17 @@ def test_conv1a_image_kernel_vs_fp64(gpu_device):
                 ref = F.leaky_relu(ref, slope)
             assert got.shape == ref.shape
             assert (got.double() - ref).abs().max().item() <= 3e-6 * 27 ** 0.5, (B, H, W, lo)
+    # a non-finite pixel poisons exactly the outputs whose 3x3 window contains it (the kernel pads K from 27 to 28 and the
+    # pad step used to multiply a REAL image value three columns to the left by a zero filter -- 0 x Inf = NaN outside the window)
+    x = torch.rand(1, 3, 64, 128, generator=g)
+    x[0, 1, 21, 40] = float("inf")
+    x[0, 2, 40, 87] = float("nan")
+    got = ops.conv3x3(x.to(gpu_device), wp, bd, 16, stride=2, leaky_slope=0.1).cpu()
+    assert "image_conv_s2_f32" in _lib.load().pwc_last_conv_kernel().decode()
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1), 0.1)
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref)) and (~torch.isfinite(ref)).sum() > 0
+    ok = torch.isfinite(ref)
+    assert (got.double()[ok] - ref[ok]).abs().max().item() <= 3e-6 * 27 ** 0.5
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
