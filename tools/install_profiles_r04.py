@@ -54,7 +54,10 @@ def main():
         if os.path.exists(os.path.join(SRC, s)):
             with open(os.path.join(SRC, s)) as f, open(os.path.join(DST, d), "w") as o:
                 o.writelines(line for line in f if line.startswith(keep))
-    summary = open(os.path.join(SRC, "pmc_summary.txt")).read()
+    try:
+        summary = open(os.path.join(SRC, "pmc_summary.txt")).read()
+    except OSError:
+        summary = ""        # part 2 (PMC passes) not collected yet: the traffic records are left out
     kib = 1024.0
     known = 1 << 30                                                     # bytes tools/calib_fetch.py streams per launch
     cal = {}
