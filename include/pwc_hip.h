@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 10
+#define PWC_ABI_VERSION 11
 
 /* element types */
 #define PWC_F32 0
@@ -70,6 +70,8 @@ const char *pwc_last_error(void);
  *   "conv_wino4" [PWC_CONV_WINO4] 1, "w4_tailsplit" [PWC_W4_TAILSPLIT] 1, "w4_smallsplit" [PWC_W4_SMALLSPLIT] 1,
  *   "corr_pipe" [PWC_CORR_PIPE] 0 (plain correlation on the round-4 pipelined kernels), "corr_roll" [PWC_CORR_ROLL] 1 (their rolling form),
  *   "corr_pipe_min_tiles" [PWC_CORR_PIPE_MIN_TILES] 1024 (8x32 tiles a launch needs for the round-4 kernels),
+ *   "corr_small_tiles" [PWC_CORR_SMALL_TILES] 48 (launches of at most this many 8x32 tiles use the small-map correlation kernel, and
+ *   pwc_warp_corr81_preferred sends them to pwc_warp_fwd + pwc_corr_fwd; 0: the tiled kernels always),
  *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off).
  * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */
 int pwc_set_option(const char *name, int value);
@@ -94,12 +96,16 @@ int pwc_corr_fwd(const void *in1, const void *in2, void *out,
  * corr = self.corr(c1, self.warp(c2, up_flow * s)); the warped tensor has no other consumer):
  *   out[b, (dy+4)*9 + (dx+4), y, x] = scale * sum_c in1[b,c,y,x] * warp(x2, flow_scale * flo)[b,c,y+dy,x+dx]   (+ LeakyReLU)
  * with pwc_warp_fwd's sampling / mask rule and pwc_corr_fwd's PWC configuration (pad 4, kernel 1, max displacement 4, strides 1);
- * bit-identical to pwc_warp_fwd followed by pwc_corr_fwd.  f32 only.  Returns PWC_EUNSUPPORTED (nothing launched) unless
+ * bit-identical to pwc_warp_fwd followed by pwc_corr_fwd on its tiled kernels (launches of more than "corr_small_tiles" 8x32 tiles;
+ * below that pwc_corr_fwd runs its small-map kernel, which sums the channels in another order).  f32 only.  Returns PWC_EUNSUPPORTED (nothing launched) unless
  * W % 4 == 0 and in1 / x2 / out are 16-byte aligned: call the two separate entry points then. */
 int pwc_warp_corr81_fwd(const void *in1, const void *x2, const void *flo, void *out, int B, int C, int H, int W,
                         float flow_scale, int align_corners, float mask_threshold,
                         float corr_multiply, unsigned flags, float leaky_slope,
                         int64_t in1_bstride, int64_t x2_bstride, int64_t flo_bstride, int64_t out_bstride, void *stream);
+/* 1 when the fused kernel is the faster way to warp + correlate this geometry, 0 for maps of a few tiles (levels 6-4, one-pair
+ * inference), where pwc_warp_fwd + pwc_corr_fwd (small-map kernel) win by ~3x, the extra launch included. */
+int pwc_warp_corr81_preferred(int B, int C, int H, int W);
 
 /* Gradients of pwc_corr_fwd w.r.t. in1 and in2 (no fused activation; same scale rule as forward), for ANY
  * (pad_size, kernel_size, max_disp, stride1, stride2) like the reference's backward (correlation_cuda_kernel.cu:150-334);

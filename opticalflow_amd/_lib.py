@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
 LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
@@ -32,6 +32,7 @@ SIGNATURES = {
     "pwc_corr_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_float,
                              c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_warp_corr81_preferred": (c_int, [c_int, c_int, c_int, c_int]),
     "pwc_warp_corr81_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_float,
                                     c_float, c_uint, c_float, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "pwc_corr_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

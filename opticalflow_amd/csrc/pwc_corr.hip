@@ -702,6 +702,78 @@ corr81_bwd_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
     }
 }
 
+// ---- small maps (pyramid levels 6-4, batch-1 inference) ----------------------------------------------------------------------------
+// The tiled kernels above give a workgroup an 8x32-pixel tile and walk the channels in 4-channel chunks through an LDS ring: with
+// a handful of tiles per launch (level 6: ONE 7x16 map per image, 196 channels = 49 chunks) the launch is a chain of DMA round
+// trips on a few CUs -- 35 us at every batch size up to 16.  Here the parallelism comes from the displacements and the channels
+// instead: a workgroup = 64 consecutive pixels x one displacement row (9 outputs per pixel), its four waves take every fourth
+// channel straight from L2 (buffer loads: the zero padding is the range check, the channel a wave-uniform offset), and add up
+// through LDS in a fixed order.  Same operator, another summation order than the tiled kernels (a chain per channel quarter instead
+// of one over all channels): equal to them within fp32 rounding, bit-repeatable, independent of the batch slot.
+constexpr int kSmallWaves = 4;
+__global__ void __launch_bounds__(64 * kSmallWaves)
+corr81_small_kernel(const float *__restrict__ in1, const float *__restrict__ in2, float *__restrict__ out, int C, int H, int W, int npb,
+                    int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky) {
+    __shared__ float red[kSmallWaves][kND][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int dy = bid % kND;
+    bid /= kND;
+    const int pb = bid % npb, b = bid / npb;
+    const int plane = H * W;
+    const int p = pb * 64 + lane;
+    const int py = p / W, px = p - py * W;
+    const int y2 = py + dy - kD;
+    const bool rowok = (p < plane) && (y2 >= 0) && (y2 < H);
+    unsigned off2[kND];
+#pragma unroll
+    for (int dx = 0; dx < kND; ++dx) {
+        const int x2 = px + dx - kD;
+        off2[dx] = (rowok && x2 >= 0 && x2 < W) ? (unsigned)(y2 * W + x2) * 4u : kOOBv;
+    }
+    const unsigned off1 = (p < plane) ? (unsigned)p * 4u : kOOBv;
+    const int nbytes = __builtin_amdgcn_readfirstlane(C * plane * 4);
+    __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(pwc::uniform_ptr(in1 + (int64_t)b * bs1), 0, nbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(pwc::uniform_ptr(in2 + (int64_t)b * bs2), 0, nbytes, 0x00020000);
+    float acc[kND];
+#pragma unroll
+    for (int dx = 0; dx < kND; ++dx) acc[dx] = 0.f;
+    auto ld1 = [&](int c) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, off1, __builtin_amdgcn_readfirstlane(c * plane * 4), 0)); };
+    auto ld2 = [&](int c, int dx) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, off2[dx], __builtin_amdgcn_readfirstlane(c * plane * 4), 0)); };
+    int c = wave;
+    for (; c + 3 * kSmallWaves < C; c += 4 * kSmallWaves) {          // four channels' 40 loads in flight per wave
+        float a[4], v[4][kND];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = ld1(c + u * kSmallWaves);
+#pragma unroll
+            for (int dx = 0; dx < kND; ++dx) v[u][dx] = ld2(c + u * kSmallWaves, dx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int dx = 0; dx < kND; ++dx) acc[dx] = fmaf(a[u], v[u][dx], acc[dx]);
+    }
+    for (; c < C; c += kSmallWaves) {
+        const float a = ld1(c);
+#pragma unroll
+        for (int dx = 0; dx < kND; ++dx) acc[dx] = fmaf(a, ld2(c, dx), acc[dx]);
+    }
+#pragma unroll
+    for (int dx = 0; dx < kND; ++dx) red[wave][dx][lane] = acc[dx];
+    __syncthreads();
+    float *po = out + (int64_t)b * bso + (int64_t)dy * kND * plane;
+    for (int i = tid; i < kND * 64; i += 64 * kSmallWaves) {
+        const int dx = i >> 6, l = i & 63, pp = pb * 64 + l;
+        if (pp >= plane) continue;
+        float v = ((red[0][dx][l] + red[1][dx][l]) + red[2][dx][l]) + red[3][dx][l];
+        v *= scale;
+        if (do_leaky) v = pwc::leaky(v, slope);
+        po[(int64_t)dx * plane + pp] = v;
+    }
+}
+
 template <typename T>
 int launch_corr(const void *in1, const void *in2, void *out, int B, int C, int H, int W,
                 int pad, int ksz, int max_disp, int s1, int s2, float scale, unsigned flags, float slope,
@@ -730,6 +802,12 @@ int launch_corr(const void *in1, const void *in2, void *out, int B, int C, int H
                               reinterpret_cast<uintptr_t>(out)) & (uintptr_t)(va * elt - 1)) == 0;
         const int vec = (W % 4 == 0) && ptr_ok && (bs1 % 4 == 0) && (bs2 % 4 == 0) && (bso % 4 == 0);
         if constexpr (sizeof(T) == 4) {
+            if (nblk <= pwc::option(pwc::OPT_CORR_SMALL_TILES) && (int64_t)C * H * W * 4 < 0x7fffffffLL) {      // small maps: see corr81_small_kernel
+                const int npb = (H * W + 63) / 64;
+                hipLaunchKernelGGL(corr81_small_kernel, dim3((unsigned)(B * npb * kND)), dim3(64 * kSmallWaves), 0, st,
+                                   a, b, o, C, H, W, npb, bs1, bs2, bso, scale, slope, do_leaky);
+                return pwc::check_launch("corr81_small_kernel");
+            }
             if (vec && pwc::corr81_pipe_enabled() && pwc::corr81_pipe_fits(B, C, H, W))      // large levels: pwc_corr_pipe.hip
                 return pwc::launch_corr81_pipe(a, b, o, B, C, H, W, bs1, bs2, bso, scale, slope, do_leaky, st);
             if (vec && (int64_t)H * W * kCKd * 4 < 0x7fffffffLL) {
@@ -813,6 +891,14 @@ extern "C" int pwc_warp_corr81_fwd(const void *in1, const void *x2, const void *
                        tiles_x, tiles_y, (int)nblk, in1_bstride, x2_bstride, out_bstride, scale, leaky_slope,
                        (flags & PWC_ACT_LEAKY) ? 1 : 0, wa);
     return pwc::check_launch("corr81_dma_kernel<warp>");
+}
+
+// Is the fused kernel the faster way to warp + correlate this geometry?  Not for maps of a few tiles: there pwc_warp_fwd followed by
+// pwc_corr_fwd (its small-map kernel) wins by 3x, launch included (profiles/r04_corr_notes.md section 6).
+extern "C" int pwc_warp_corr81_preferred(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t nblk = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + kTH - 1) / kTH);
+    return nblk > pwc::option(pwc::OPT_CORR_SMALL_TILES) ? 1 : 0;
 }
 
 extern "C" int pwc_corr_bwd(const void *in1, const void *in2, const void *grad_out, void *grad_in1, void *grad_in2,

@@ -384,9 +384,9 @@ class PwcPlan:
         ar[:, off:off + c].copy_(self.c1[l])
         up_flow = ar[:, off + c:off + c + 2]
         # warp + correlation + LeakyReLU as one kernel (the warped features live in LDS only) where the geometry
-        # allows it (md = 4, W % 4 == 0); otherwise the two operators
+        # allows it (md = 4, W % 4 == 0) and the map is more than a few tiles; otherwise the two operators
         fused = None
-        if self.fuse_warp and self.md == 4:
+        if self.fuse_warp and self.md == 4 and ops.warp_correlation_preferred(ar.shape[0], c, *self.size[l]):
             fused = ops.warp_correlation(ar[:, off:off + c], self.c2[l], up_flow, flow_scale=WARP_SCALE[l],
                                          align_corners=self.align_corners, mask_threshold=self.mask_threshold,
                                          normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)

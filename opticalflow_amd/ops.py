@@ -118,6 +118,12 @@ def correlation_backward(in1: torch.Tensor, in2: torch.Tensor, grad_out: torch.T
     return g1, g2
 
 
+def warp_correlation_preferred(B: int, C: int, H: int, W: int) -> bool:
+    """Whether the fused warp + correlation kernel beats warp() followed by correlation() for this geometry (rule in the library:
+    not for maps of a few tiles, where the small-map correlation kernel wins)."""
+    return bool(_lib.load().pwc_warp_corr81_preferred(B, C, H, W))
+
+
 def warp_correlation(in1: torch.Tensor, x2: torch.Tensor, flo: torch.Tensor, flow_scale: float = 1.0,
                      align_corners: bool = False, mask_threshold: float = 0.9999, corr_multiply: float = 1.0,
                      normalize: bool = False, leaky_slope: Optional[float] = None,

@@ -150,12 +150,15 @@ def test_corr_properties_full_size(dev):
 
 @pytest.mark.parametrize("shape,scale,align", [((2, 32, 24, 64), 5.0, False), ((1, 64, 56, 128), 2.5, True), ((3, 13, 20, 44), 1.25, False),
                                                ((2, 128, 14, 32), 0.625, False), ((16, 32, 112, 256), 5.0, False)])
-def test_warp_correlation_fused_equals_two_kernels(dev, shape, scale, align):
+def test_warp_correlation_fused_equals_two_kernels(dev, request, shape, scale, align):
     """pwc_warp_corr81_fwd (warp producer waves + LDS-DMA loader + nine fma waves in one persistent kernel) is BIT-IDENTICAL to
     pwc_warp_fwd followed by pwc_corr_fwd -- flows that leave the image, ragged tiles, ragged channel chunks, arena-strided
     operands, both scale modes -- and agrees with the oracle."""
-    from opticalflow_amd import ops
+    from opticalflow_amd import ops, _lib
     B, C, H, W = shape
+    # maps of a few tiles would send pwc_corr_fwd to its small-map kernel (another summation order: test_corr_small_map_kernel)
+    request.addfinalizer(lambda: _lib.set_option("corr_small_tiles", 48))
+    _lib.set_option("corr_small_tiles", 0)
     c1 = seeded_rand(shape, 70, -1, 1).to(dev)
     c2 = seeded_rand(shape, 71, -1, 1).to(dev)
     flo = seeded_rand((B, 2, H, W), 72, -3, 3)
@@ -1414,3 +1417,42 @@ def test_conv3x3_winograd4_narrow_maps(gpu_device, case):
     kern = _lib.load().pwc_last_conv_kernel().decode()
     assert "wino4p" in kern and ", 32," in kern, kern              # <CB, TG, GW = 32, ...>
     assert (got.double() - ref).abs().max().item() <= 1e-6 * (cin * 9) ** 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 196, 7, 16), (16, 196, 7, 16), (2, 128, 14, 32), (1, 96, 28, 64), (1, 64, 56, 128), (3, 37, 9, 33), (2, 5, 3, 2)])
+def test_corr_small_map_kernel(gpu_device, shape):
+    """Launches of at most "corr_small_tiles" 8x32 tiles (levels 6-4 at batch 16, levels 6-3 of a single pair) run
+    corr81_small_kernel: a workgroup per (64 pixels, displacement row), channels split over its four waves and added up in a fixed
+    order.  Against the oracle (correlation.py:12-40) and the tiled kernel (same operator, other summation order: fp32 rounding
+    only), LeakyReLU and an arena slot as the output, odd widths, maps smaller than the displacement range; bit-repeatable and
+    independent of the batch slot; pwc_warp_corr81_preferred hands these geometries to warp + correlation."""
+    from opticalflow_amd import ops, _lib
+    B, C, H, W = shape
+    dev = gpu_device
+    a = seeded_rand(shape, 310, -1, 1)
+    b = seeded_rand(shape, 311, -1, 1)
+    if B > 1:
+        a[-1], b[-1] = a[0], b[0]                                       # same pair in the first and the last slot
+    ad, bd = a.to(dev), b.to(dev)
+    arena = torch.full((B, 81 + 3, H, W), 7.0, device=dev)
+    ops.correlation(ad, bd, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1, out=arena[:, 1:82])
+    got = arena[:, 1:82]
+    assert (arena[:, :1] == 7).all() and (arena[:, 82:] == 7).all()
+    ref = O.leaky_relu(O.correlation(a, b, 4, 1, 4, 1, 1, 1))
+    tol = 2e-6 * C ** 0.5 * max(1.0, ref.abs().max().item())
+    assert (got.cpu() - ref).abs().max().item() <= tol
+    assert torch.equal(ops.correlation(ad, bd, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1), got)
+    if B > 1:
+        assert torch.equal(got[0], got[-1])
+    assert not ops.warp_correlation_preferred(B, C, H, W)
+    _lib.set_option("corr_small_tiles", 0)
+    try:
+        tiled = ops.correlation(ad, bd, 4, 1, 4, 1, 1, 1.0, leaky_slope=0.1)
+        assert ops.warp_correlation_preferred(B, C, H, W)
+    finally:
+        _lib.set_option("corr_small_tiles", 48)
+    d = (tiled - got).abs().max().item()
+    assert d <= tol, d
+    norm = ops.correlation(ad, bd, 4, 1, 4, 1, 1, 1.0, normalize=True)
+    assert (norm.cpu() - O.correlation(a, b, 4, 1, 4, 1, 1, 1) / C).abs().max().item() <= tol / C
