@@ -72,6 +72,8 @@ const char *pwc_last_error(void);
  *   "corr_pipe_min_tiles" [PWC_CORR_PIPE_MIN_TILES] 1024 (8x32 tiles a launch needs for the round-4 kernels),
  *   "corr_small_tiles" [PWC_CORR_SMALL_TILES] 48 (launches of at most this many 8x32 tiles use the small-map correlation kernel, and
  *   pwc_warp_corr81_preferred sends them to pwc_warp_fwd + pwc_corr_fwd; 0: the tiled kernels always),
+ *   "f16_level_corr" [PWC_F16_LEVEL_CORR] 0 (1: the half-precision plans enter a level through pwc_level_corr81_c8_f16 instead of the two
+ *   calls it fuses -- same bits, measured slower at batch 16),
  *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off).
  * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */
 int pwc_set_option(const char *name, int value);
@@ -292,6 +294,21 @@ int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void *flow32, c
                            int64_t c1_bstride, int64_t c2_bstride, int64_t flow32_bstride,
                            int64_t feat_phases_bstride, int64_t c1_dst_bstride, int64_t flow_group_bstride,
                            int64_t warped_bstride, void *stream);
+
+/* pwc_level_entry_c8_f16 + pwc_corr81_c8_f16 in ONE launch, the warped features staying in LDS (PWCNet.py:208-214 for a level below
+ * the coarsest): the flow group and the c1 slot of the arena are written as by pwc_level_entry_c8_f16, corr_out
+ * [B][11][H][W][8] (81 channels + 7 zeros, LeakyReLU with PWC_ACT_LEAKY, PWC_CORR_NORMALIZE as in pwc_corr81_c8_f16) as by
+ * pwc_corr81_c8_f16 on the warped tensor -- bit-identical to the two calls; no `warped` tensor is needed.  One launch less and no
+ * round trip of the warped features through HBM, but every tile gathers its 16 x 40 halo (2.5x the pixels): 97 vs 81 us at level 2
+ * of a batch of 16, faster only for single small launches; the plans keep the two calls unless option "f16_level_corr" is set. */
+int pwc_level_corr81_c8_f16(const void *c1, const void *c2, const void *flow32, const void *feat_phases,
+                            const void *deconv_w, const void *deconv_b,
+                            void *c1_dst, void *flow_group, void *corr_out, int B, int C, int H, int W,
+                            float flow_scale, int align_corners, float mask_threshold,
+                            float corr_multiply, unsigned flags, float leaky_slope,
+                            int64_t c1_bstride, int64_t c2_bstride, int64_t flow32_bstride,
+                            int64_t feat_phases_bstride, int64_t c1_dst_bstride, int64_t flow_group_bstride,
+                            int64_t corr_bstride, void *stream);
 
 /* ConvTranspose2d(kernel 4, stride 2, padding 1) + bias.  x:[B,Cin,H,W], w:[Cin,Cout,4,4] (nn layout),
  * y:[B,Cout,2H,2W]. */

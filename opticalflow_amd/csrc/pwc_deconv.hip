@@ -61,14 +61,9 @@ deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, con
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[co][0][0] = acc[co][0][1] = acc[co][1][0] = acc[co][1][1] = 0.f;
 
-    for (int ci = wave; ci < Cin; ci += kDWaves) {
-        const float *xp = xb + (int64_t)ci * plane;
-        float v[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[a][c] = xp[off[a][c]] * msk[a][c];
-        const float *wc = w + (int64_t)ci * CO * 16;          // wave-uniform
+    // one channel: its 3x3 neighbourhood (loaded by the caller) times the channel's 2 x 16 weights (wave-uniform: scalar loads)
+    auto channel = [&](int ci, const float (&v)[3][3]) {
+        const float *wc = w + (int64_t)ci * CO * 16;
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
             const float *k = wc + co * 16;                    // k[ky*4 + kx]
@@ -86,6 +81,29 @@ deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, con
                     acc[co][py][px] = s;
                 }
         }
+    };
+    auto fetch = [&](int ci, float (&v)[3][3]) {
+        const float *xp = xb + (int64_t)ci * plane;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[a][c] = xp[off[a][c]] * msk[a][c];
+    };
+    // A wave walks ~Cin / waves channels (35 for upfeat6): one channel per trip is one load round trip per trip -- 22-26 us per launch
+    // at every level of a single pair.  Three channels' 27 loads in flight per trip; same order of the additions, same bits.
+    constexpr int kU = 3;
+    int ci = wave;
+    for (; ci + (kU - 1) * kDWaves < Cin; ci += kU * kDWaves) {
+        float v[kU][3][3];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) fetch(ci + u * kDWaves, v[u]);
+#pragma unroll
+        for (int u = 0; u < kU; ++u) channel(ci + u * kDWaves, v[u]);
+    }
+    for (; ci < Cin; ci += kDWaves) {
+        float v[3][3];
+        fetch(ci, v);
+        channel(ci, v);
     }
 #pragma unroll
     for (int co = 0; co < CO; ++co)

@@ -162,57 +162,39 @@ struct LevelEntry {
 };
 
 
-template <bool ENTRY>
-__global__ void __launch_bounds__(256)
-warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo, _Float16 *__restrict__ out,
-               int Cg, int H, int W, int64_t npix, int flo_channel, int64_t bsx, int64_t bsf, int64_t bso,
-               float flow_scale, int align_corners, float thr, LevelEntry e) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix) return;
-    const int64_t plane = (int64_t)H * W;
-    const int b = (int)(i / plane);
-    const int pix = (int)(i - (int64_t)b * plane);
-    const int yy = pix / W, xx = pix - yy * W;
-    float u, v;
-    if constexpr (ENTRY) {
-        const int hh = H >> 1, wh = W >> 1;
-        const int py = yy & 1, px = xx & 1;
-        // output row 2Y+py takes input rows r0 = Y-1+py (kernel row 3-py) and r0+1 (kernel row 1-py); same along x
-        const int r0 = (yy >> 1) - 1 + py, c0 = (xx >> 1) - 1 + px;
-        const float *fb = e.flow32 + (int64_t)b * e.bs_flow;
-        float acc0 = e.db[0], acc1 = e.db[1];
+// up_flow = deconvL(flow) at output pixel (yy, xx) of image b, in fp32 (ConvTranspose2d(2,2,k4,s2,p1): 2x2 input pixels x 2 channels)
+__device__ __forceinline__ void entry_up_flow(const LevelEntry &e, int b, int yy, int xx, int H, int W, float &acc0, float &acc1) {
+    const int hh = H >> 1, wh = W >> 1;
+    const int py = yy & 1, px = xx & 1;
+    // output row 2Y+py takes input rows r0 = Y-1+py (kernel row 3-py) and r0+1 (kernel row 1-py); same along x
+    const int r0 = (yy >> 1) - 1 + py, c0 = (xx >> 1) - 1 + px;
+    const float *fb = e.flow32 + (int64_t)b * e.bs_flow;
+    acc0 = e.db[0];
+    acc1 = e.db[1];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int r = r0 + a, ky = 3 - py - 2 * a;
+    for (int a = 0; a < 2; ++a) {
+        const int r = r0 + a, ky = 3 - py - 2 * a;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int cc = c0 + c, kx = 3 - px - 2 * c;
-                if (r < 0 || r >= hh || cc < 0 || cc >= wh) continue;
-                const float2 f = *reinterpret_cast<const float2 *>(fb + ((int64_t)r * wh + cc) * 8);
-                acc0 = fmaf(f.x, e.dw[(0 * 2 + 0) * 16 + ky * 4 + kx], acc0);
-                acc0 = fmaf(f.y, e.dw[(1 * 2 + 0) * 16 + ky * 4 + kx], acc0);
-                acc1 = fmaf(f.x, e.dw[(0 * 2 + 1) * 16 + ky * 4 + kx], acc1);
-                acc1 = fmaf(f.y, e.dw[(1 * 2 + 1) * 16 + ky * 4 + kx], acc1);
-            }
+        for (int c = 0; c < 2; ++c) {
+            const int cc = c0 + c, kx = 3 - px - 2 * c;
+            if (r < 0 || r >= hh || cc < 0 || cc >= wh) continue;
+            const float2 f = *reinterpret_cast<const float2 *>(fb + ((int64_t)r * wh + cc) * 8);
+            acc0 = fmaf(f.x, e.dw[(0 * 2 + 0) * 16 + ky * 4 + kx], acc0);
+            acc0 = fmaf(f.y, e.dw[(1 * 2 + 0) * 16 + ky * 4 + kx], acc0);
+            acc1 = fmaf(f.x, e.dw[(0 * 2 + 1) * 16 + ky * 4 + kx], acc1);
+            acc1 = fmaf(f.y, e.dw[(1 * 2 + 1) * 16 + ky * 4 + kx], acc1);
         }
-        const int64_t sp = ((int64_t)(yy >> 1) * wh + (xx >> 1)) * 8;
-        const int ph = py * 2 + px;
-        const float *pq = e.feat_phases + (int64_t)b * e.bs_featp + sp;
-        h4 o;
-        o[0] = pwc::sat_half(acc0); o[1] = pwc::sat_half(acc1); o[2] = pwc::sat_half(pq[ph]); o[3] = pwc::sat_half(pq[4 + ph]);
-        *reinterpret_cast<h4 *>(e.fg + (int64_t)b * e.bs_fg + (int64_t)pix * 8) = o;
-        u = acc0 * flow_scale;
-        v = acc1 * flow_scale;
-        const _Float16 *cs = e.c1 + (int64_t)b * e.bs_c1 + (int64_t)pix * 8;
-        _Float16 *cd = e.c1_dst + (int64_t)b * e.bs_c1dst + (int64_t)pix * 8;
-        for (int g = 0; g < Cg; ++g, cs += plane * 8, cd += plane * 8)
-            *reinterpret_cast<h8 *>(cd) = *reinterpret_cast<const h8 *>(cs);
-    } else {
-        const _Float16 *f = flo + (int64_t)b * bsf + (int64_t)pix * 8 + flo_channel;
-        u = (float)f[0] * flow_scale;
-        v = (float)f[1] * flow_scale;
     }
-    // same arithmetic as pwc_warp.hip::make_taps (PWCNet.py:162-163 + grid_sample's un-normalisation)
+}
+
+// bilinear taps of PWCDCNet.warp at pixel (xx, yy) displaced by (u, v): element offsets of the four taps inside a channel group's
+// plane and their weights (zero outside the image or under the mask threshold).  Same arithmetic as pwc_warp.hip::make_taps
+// (PWCNet.py:162-163 + grid_sample's un-normalisation).
+struct Taps8 {
+    int64_t o00, o01, o10, o11;
+    float w00, w01, w10, w11;
+};
+__device__ __forceinline__ Taps8 make_taps8(float u, float v, int xx, int yy, int H, int W, int align_corners, float thr) {
     const float gx = 2.0f * ((float)xx + u) / (float)max(W - 1, 1) - 1.0f;
     const float gy = 2.0f * ((float)yy + v) / (float)max(H - 1, 1) - 1.0f;
     float ix, iy;
@@ -230,24 +212,191 @@ warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo,
     const float ax1 = ix - fx, ay1 = iy - fy, ax0 = 1.0f - ax1, ay0 = 1.0f - ay1;
     const bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x0 + 1 >= 0) && (x0 + 1 < W);
     const bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y0 + 1 >= 0) && (y0 + 1 < H);
-    float w00 = (vx0 && vy0) ? ay0 * ax0 : 0.f, w01 = (vx1 && vy0) ? ay0 * ax1 : 0.f;
-    float w10 = (vx0 && vy1) ? ay1 * ax0 : 0.f, w11 = (vx1 && vy1) ? ay1 * ax1 : 0.f;
-    const float msum = ((w00 + w01) + w10) + w11;
-    if (!(msum >= thr)) w00 = w01 = w10 = w11 = 0.f;
+    Taps8 t;
+    t.w00 = (vx0 && vy0) ? ay0 * ax0 : 0.f;
+    t.w01 = (vx1 && vy0) ? ay0 * ax1 : 0.f;
+    t.w10 = (vx0 && vy1) ? ay1 * ax0 : 0.f;
+    t.w11 = (vx1 && vy1) ? ay1 * ax1 : 0.f;
+    const float msum = ((t.w00 + t.w01) + t.w10) + t.w11;
+    if (!(msum >= thr)) t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
     const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
     const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
-    const int64_t o00 = ((int64_t)yc0 * W + xc0) * 8, o01 = ((int64_t)yc0 * W + xc1) * 8;
-    const int64_t o10 = ((int64_t)yc1 * W + xc0) * 8, o11 = ((int64_t)yc1 * W + xc1) * 8;
+    t.o00 = ((int64_t)yc0 * W + xc0) * 8;
+    t.o01 = ((int64_t)yc0 * W + xc1) * 8;
+    t.o10 = ((int64_t)yc1 * W + xc0) * 8;
+    t.o11 = ((int64_t)yc1 * W + xc1) * 8;
+    return t;
+}
+__device__ __forceinline__ h8 blend_taps8(const _Float16 *src, const Taps8 &t) {
+    const h8 a = *reinterpret_cast<const h8 *>(src + t.o00), bq = *reinterpret_cast<const h8 *>(src + t.o01);
+    const h8 c = *reinterpret_cast<const h8 *>(src + t.o10), d = *reinterpret_cast<const h8 *>(src + t.o11);
+    h8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = (_Float16)((((float)a[j] * t.w00 + (float)bq[j] * t.w01) + (float)c[j] * t.w10) + (float)d[j] * t.w11);
+    return o;
+}
+
+template <bool ENTRY>
+__global__ void __launch_bounds__(256)
+warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo, _Float16 *__restrict__ out,
+               int Cg, int H, int W, int64_t npix, int flo_channel, int64_t bsx, int64_t bsf, int64_t bso,
+               float flow_scale, int align_corners, float thr, LevelEntry e) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int64_t plane = (int64_t)H * W;
+    const int b = (int)(i / plane);
+    const int pix = (int)(i - (int64_t)b * plane);
+    const int yy = pix / W, xx = pix - yy * W;
+    float u, v;
+    if constexpr (ENTRY) {
+        float acc0, acc1;
+        entry_up_flow(e, b, yy, xx, H, W, acc0, acc1);
+        const int64_t sp = ((int64_t)(yy >> 1) * (W >> 1) + (xx >> 1)) * 8;
+        const int ph = (yy & 1) * 2 + (xx & 1);
+        const float *pq = e.feat_phases + (int64_t)b * e.bs_featp + sp;
+        h4 o;
+        o[0] = pwc::sat_half(acc0); o[1] = pwc::sat_half(acc1); o[2] = pwc::sat_half(pq[ph]); o[3] = pwc::sat_half(pq[4 + ph]);
+        *reinterpret_cast<h4 *>(e.fg + (int64_t)b * e.bs_fg + (int64_t)pix * 8) = o;
+        u = acc0 * flow_scale;
+        v = acc1 * flow_scale;
+        const _Float16 *cs = e.c1 + (int64_t)b * e.bs_c1 + (int64_t)pix * 8;
+        _Float16 *cd = e.c1_dst + (int64_t)b * e.bs_c1dst + (int64_t)pix * 8;
+        for (int g = 0; g < Cg; ++g, cs += plane * 8, cd += plane * 8)
+            *reinterpret_cast<h8 *>(cd) = *reinterpret_cast<const h8 *>(cs);
+    } else {
+        const _Float16 *f = flo + (int64_t)b * bsf + (int64_t)pix * 8 + flo_channel;
+        u = (float)f[0] * flow_scale;
+        v = (float)f[1] * flow_scale;
+    }
+    const Taps8 t = make_taps8(u, v, xx, yy, H, W, align_corners, thr);
     const _Float16 *src = x + (int64_t)b * bsx;
     _Float16 *dst = out + (int64_t)b * bso + (int64_t)pix * 8;
-    for (int g = 0; g < Cg; ++g, src += plane * 8, dst += plane * 8) {
-        const h8 a = *reinterpret_cast<const h8 *>(src + o00), bq = *reinterpret_cast<const h8 *>(src + o01);
-        const h8 c = *reinterpret_cast<const h8 *>(src + o10), d = *reinterpret_cast<const h8 *>(src + o11);
+    for (int g = 0; g < Cg; ++g, src += plane * 8, dst += plane * 8) *reinterpret_cast<h8 *>(dst) = blend_taps8(src, t);
+}
+
+// ---- level entry + warp + correlation in ONE kernel (VERDICT r3 next #1c) ----------------------------------------------------------
+// corr81_c8_kernel with the LDS-DMA of the in2 halo tile replaced by its production: the 256 threads of a tile own its 16 x 40 halo
+// pixels (three slots each, the last one part-filled), compute up_flow there exactly as the entry kernel does (fp32 deconvolution of
+// the level above's fp32 flow), derive the bilinear taps ONCE per tile and, per step of four channel groups, gather four 16-byte taps
+// per (pixel, group), blend in fp32 and write the half result into the LDS tile -- the warped tensor never exists in memory.  The
+// thread's own pixel does the rest of the level's entry on the way: (up_flow, up_feat) into the arena's flow group, and the c1 values
+// it loads for the dot products anyway are also stored into the arena.  One launch instead of two, and 58 MB (level 2, batch 16) of
+// warped features + 29 MB of c1 re-read less.  Statement-for-statement the arithmetic of warp_c8_kernel<true> + corr81_c8_kernel:
+// bit-identical results.
+constexpr int kCHaloPx = kCHaloH * kCHaloW;                      // 640
+constexpr int kCSlots = (kCHaloPx + kCThreads - 1) / kCThreads;  // 3
+
+__global__ void __launch_bounds__(kCThreads, 3)
+level_corr81_c8_kernel(const _Float16 *__restrict__ x2, _Float16 *__restrict__ out, int Cg, int H, int W, int tiles_x, int tiles_y,
+                       int64_t bsx, int64_t bso, float flow_scale, int align_corners, float thr, LevelEntry e,
+                       float scale, float slope, int do_leaky) {
+    __shared__ __attribute__((aligned(16))) h8 tile[kCPieces];           // [g][row 16][col 40]
+
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = tx * kCTW, y0 = ty * kCTH;
+    const int plane = H * W;
+    const int px = tid & 31, py = tid >> 5;
+    const int x = x0 + px, y = y0 + py;
+    const bool inside = (x < W) && (y < H);
+
+    // the thread's own pixel: flow group of the arena (deconvL / upfeatL of the level above)
+    if (inside) {
+        float acc0, acc1;
+        entry_up_flow(e, b, y, x, H, W, acc0, acc1);
+        const int64_t sp = ((int64_t)(y >> 1) * (W >> 1) + (x >> 1)) * 8;
+        const int ph = (y & 1) * 2 + (x & 1);
+        const float *pq = e.feat_phases + (int64_t)b * e.bs_featp + sp;
+        h4 o;
+        o[0] = pwc::sat_half(acc0); o[1] = pwc::sat_half(acc1); o[2] = pwc::sat_half(pq[ph]); o[3] = pwc::sat_half(pq[4 + ph]);
+        *reinterpret_cast<h4 *>(e.fg + (int64_t)b * e.bs_fg + ((int64_t)y * W + x) * 8) = o;
+    }
+    // the thread's halo pixels: taps once per tile (a halo pixel outside the image is the correlation's zero padding)
+    Taps8 taps[kCSlots];
+    bool live[kCSlots];
+#pragma unroll
+    for (int i = 0; i < kCSlots; ++i) {
+        const int hp = tid + i * kCThreads;
+        const int hy = y0 - 4 + hp / kCHaloW, hx = x0 - 4 + hp % kCHaloW;
+        live[i] = (hp < kCHaloPx) && (hy >= 0) && (hy < H) && (hx >= 0) && (hx < W);
+        float u = 0.f, v = 0.f;
+        if (live[i]) {
+            entry_up_flow(e, b, hy, hx, H, W, u, v);
+            u *= flow_scale;
+            v *= flow_scale;
+        }
+        taps[i] = make_taps8(u, v, live[i] ? hx : 0, live[i] ? hy : 0, H, W, align_corners, thr);
+    }
+
+    float acc[81];
+#pragma unroll
+    for (int d = 0; d < 81; ++d) acc[d] = 0.f;
+
+    const _Float16 *p1 = e.c1 + (int64_t)b * e.bs_c1;
+    _Float16 *pc = e.c1_dst + (int64_t)b * e.bs_c1dst;
+    const _Float16 *p2 = x2 + (int64_t)b * bsx;
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int g0 = 0; g0 < Cg; g0 += kCGroups) {
+        const int gv = min(kCGroups, Cg - g0);
+        __syncthreads();                                   // previous step's reads are done
+#pragma unroll
+        for (int i = 0; i < kCSlots; ++i) {
+            const int hp = tid + i * kCThreads;
+            if (hp >= kCHaloPx) continue;
+            // UNCONDITIONAL loads (a dead pixel's taps point at element 0, a group past the last one re-reads the last): a load behind
+            // a run-time condition makes hipcc branch around it and wait for each one (cdna guide, GEMV item 4c); the selects are
+            // v_cndmask.  The 16 taps of a pixel's four groups are in flight together.
+#pragma unroll
+            for (int gp = 0; gp < kCGroups; gp += 2) {     // two groups' eight taps in flight (four would cost a third workgroup per CU)
+                h8 r[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const h8 v = blend_taps8(p2 + (int64_t)(g0 + min(gp + k, gv - 1)) * plane * 8, taps[i]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[k][j] = live[i] ? v[j] : (_Float16)0;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (gp + k < gv) tile[(gp + k) * kCHaloPx + hp] = r[k];
+            }
+        }
+        __syncthreads();
+        for (int g = 0; g < gv; ++g) {
+            h8 a = zero;
+            if (inside) {
+                const int64_t o1 = ((int64_t)(g0 + g) * plane + (int64_t)y * W + x) * 8;
+                a = *reinterpret_cast<const h8 *>(p1 + o1);
+                *reinterpret_cast<h8 *>(pc + o1) = a;                   // c1 into its arena slot
+            }
+            const h8 *t = tile + (g * kCHaloH + py) * kCHaloW + px;
+#pragma unroll
+            for (int dy = 0; dy < 9; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 9; ++dx)
+                    acc[dy * 9 + dx] = dot8(a, t[dy * kCHaloW + dx], acc[dy * 9 + dx]);
+        }
+    }
+    if (!inside) return;
+    _Float16 *po = out + (int64_t)b * bso + ((int64_t)y * W + x) * 8;
+#pragma unroll
+    for (int g = 0; g < 11; ++g) {
         h8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            o[j] = (_Float16)((((float)a[j] * w00 + (float)bq[j] * w01) + (float)c[j] * w10) + (float)d[j] * w11);
-        *reinterpret_cast<h8 *>(dst) = o;
+        for (int j = 0; j < 8; ++j) {
+            const int d = g * 8 + j;
+            float v = 0.f;
+            if (d < 81) {
+                v = acc[d < 81 ? d : 0] * scale;
+                if (do_leaky) v = pwc::leaky(v, slope);
+            }
+            o[j] = pwc::sat_half(v);
+        }
+        *reinterpret_cast<h8 *>(po + (int64_t)g * plane * 8) = o;
     }
 }
 
@@ -409,4 +558,46 @@ extern "C" int pwc_level_entry_c8_f16(const void *c1, const void *c2, const void
                        (C + 7) / 8, H, W, npix, 0, c2_bstride, (int64_t)0, warped_bstride,
                        flow_scale, align_corners, mask_threshold, e);
     return pwc::check_launch("warp_c8_kernel<entry>");
+}
+
+/* Entry of a decoder level below the coarsest AND its cost volume in one launch (PWCNet.py:208-214: up_flow = deconvL(flow),
+ * up_feat = upfeatL(x), corr = LeakyReLU(corr(c1, warp(c2, up_flow * s)))): pwc_level_entry_c8_f16 followed by pwc_corr81_c8_f16
+ * with the warped features kept in LDS.  Bit-identical to the two calls. */
+extern "C" int pwc_level_corr81_c8_f16(const void *c1, const void *c2, const void *flow32, const void *feat_phases,
+                                       const void *deconv_w, const void *deconv_b,
+                                       void *c1_dst, void *flow_group, void *corr_out, int B, int C, int H, int W,
+                                       float flow_scale, int align_corners, float mask_threshold,
+                                       float corr_multiply, unsigned flags, float leaky_slope,
+                                       int64_t c1_bstride, int64_t c2_bstride, int64_t flow32_bstride,
+                                       int64_t feat_phases_bstride, int64_t c1_dst_bstride, int64_t flow_group_bstride,
+                                       int64_t corr_bstride, void *stream) {
+    if (!c1 || !c2 || !flow32 || !feat_phases || !deconv_w || !deconv_b || !c1_dst || !flow_group || !corr_out)
+        PWC_FAIL(PWC_EINVAL, "pwc_level_corr81_c8_f16: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
+        PWC_FAIL(PWC_EINVAL, "pwc_level_corr81_c8_f16: H and W must be positive and even (twice the level above), got %dx%d", H, W);
+    const void *ptrs[7] = {c1, c2, flow32, feat_phases, c1_dst, flow_group, corr_out};
+    const int64_t strides[7] = {c1_bstride, c2_bstride, flow32_bstride, feat_phases_bstride, c1_dst_bstride,
+                                flow_group_bstride, corr_bstride};
+    for (int k = 0; k < 7; ++k)
+        if (!pwc::aligned16(ptrs[k]) || (strides[k] % 8))
+            PWC_FAIL(PWC_EALIGN, "pwc_level_corr81_c8_f16: tensors must be 16-byte aligned with batch strides that are multiples of 8");
+    if (c1 == c1_dst) PWC_FAIL(PWC_EINVAL, "pwc_level_corr81_c8_f16: in-place operands");
+    const int cg = (C + 7) / 8;
+    const int64_t plane = (int64_t)H * W;
+    if (c1_bstride < cg * plane * 8 || c2_bstride < cg * plane * 8 || c1_dst_bstride < cg * plane * 8 || corr_bstride < 11 * plane * 8 ||
+        flow_group_bstride < plane * 8)
+        PWC_FAIL(PWC_EINVAL, "pwc_level_corr81_c8_f16: batch stride smaller than the tensor");
+    const int tiles_x = (W + kCTW - 1) / kCTW, tiles_y = (H + kCTH - 1) / kCTH;
+    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_level_corr81_c8_f16: grid too large");
+    const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
+    LevelEntry e{static_cast<const float *>(flow32), static_cast<const float *>(feat_phases),
+                 static_cast<const float *>(deconv_w), static_cast<const float *>(deconv_b),
+                 static_cast<const _Float16 *>(c1), static_cast<_Float16 *>(flow_group), static_cast<_Float16 *>(c1_dst),
+                 flow32_bstride, feat_phases_bstride, c1_bstride, flow_group_bstride, c1_dst_bstride};
+    hipLaunchKernelGGL(level_corr81_c8_kernel, dim3((unsigned)nblk), dim3(kCThreads), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const _Float16 *>(c2), static_cast<_Float16 *>(corr_out), cg, H, W, tiles_x, tiles_y,
+                       c2_bstride, corr_bstride, flow_scale, align_corners, mask_threshold, e,
+                       scale, leaky_slope, (flags & PWC_ACT_LEAKY) ? 1 : 0);
+    return pwc::check_launch("level_corr81_c8_kernel");
 }

@@ -29,7 +29,7 @@ from typing import Dict
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from . import ops_f16 as F16
 from .engine import (CONTEXT, DENSE_OUT, LEAKY, PYRAMID_CH, PYRAMID_NAMES, PYRAMID_NAMES_OLD, WARP_SCALE, level_in_channels,
                      old_variant_perm)
@@ -158,6 +158,7 @@ class PwcPlanF16:
             self.pyr_a[l] = torch.zeros((self._slots(B), g, h, w, 8), **hk)
             self.pyr_b[l] = torch.zeros((self._slots(B), g, h, w, 8), **hk)
         self.arena, self.warped, self.head = {}, {}, {}
+        self.fused_entry = _lib.get_option("f16_level_corr") > 0      # level entry + warp + cost volume as one kernel (warped: LDS only)
         for l in range(2, 7):
             h, w = self.size[l]
             g = _groups(PYRAMID_CH[l])
@@ -274,15 +275,19 @@ class PwcPlanF16:
             if l == 6:
                 F16.correlation_c8(c1, c2, PYRAMID_CH[6], normalize=self.normalize_corr, leaky_slope=LEAKY, out=corr_slot)
             else:
-                # one launch: pixel-shuffle deconv / upfeat of the level above into the flow group, c1 into the arena, warp
+                # pixel-shuffle deconv / upfeat of the level above into the flow group, c1 into the arena, warp; then the cost volume.
+                # Option f16_level_corr = 1: all of it as ONE launch with the warped features in LDS only -- same bits, but slower at
+                # batch 16 (each tile gathers its whole halo), so it is opt-in
                 f0 = BASE_G + CORR_G
-                F16.level_entry(c1, c2, self.head[l + 1][:, 0:1], self.head[l + 1][:, 1:2], self.deconv_w[l + 1],
-                                self.deconv_b[l + 1], PYRAMID_CH[l],
-                                c1_dst=ar[:, f0:f0 + g], flow_group=ar[:, f0 + g:f0 + g + 1], out=self.warped[l],
-                                flow_scale=WARP_SCALE[l], align_corners=self.align_corners,
-                                mask_threshold=self.mask_threshold)
-                F16.correlation_c8(c1, self.warped[l], PYRAMID_CH[l], normalize=self.normalize_corr, leaky_slope=LEAKY,
-                                   out=corr_slot)
+                kw = dict(c1_dst=ar[:, f0:f0 + g], flow_group=ar[:, f0 + g:f0 + g + 1], flow_scale=WARP_SCALE[l],
+                          align_corners=self.align_corners, mask_threshold=self.mask_threshold)
+                args = (c1, c2, self.head[l + 1][:, 0:1], self.head[l + 1][:, 1:2], self.deconv_w[l + 1], self.deconv_b[l + 1], PYRAMID_CH[l])
+                if self.fused_entry:
+                    F16.level_entry_correlation(*args, out=corr_slot, normalize=self.normalize_corr, leaky_slope=LEAKY, **kw)
+                else:
+                    F16.level_entry(*args, out=self.warped[l], **kw)
+                    F16.correlation_c8(c1, self.warped[l], PYRAMID_CH[l], normalize=self.normalize_corr, leaky_slope=LEAKY,
+                                       out=corr_slot)
             lo = BASE_G
             for i, og in enumerate(DENSE_G):
                 self._conv("conv%d_%d" % (l, i), ar[:, lo:], ar[:, og:og + DENSE_OUT[i] // 8])

@@ -210,6 +210,38 @@ def level_entry(c1: torch.Tensor, c2: torch.Tensor, flow32: torch.Tensor, feat_p
     return out
 
 
+def level_entry_correlation(c1: torch.Tensor, c2: torch.Tensor, flow32: torch.Tensor, feat_phases: torch.Tensor,
+                            deconv_w: torch.Tensor, deconv_b: torch.Tensor, channels: int,
+                            c1_dst: torch.Tensor, flow_group: torch.Tensor, out: torch.Tensor, flow_scale: float = 1.0,
+                            align_corners: bool = False, mask_threshold: float = 0.9999, corr_multiply: float = 1.0,
+                            normalize: bool = False, leaky_slope: Optional[float] = None) -> torch.Tensor:
+    """level_entry() followed by correlation_c8(c1, warped) as ONE kernel (PWCNet.py:208-214): the warped features stay in LDS,
+    `out` is the cost volume [B,11,H,W,8]; flow_group and c1_dst are written as by level_entry().  Bit-identical to the two calls."""
+    lib = _lib.load()
+    B, cg, H, W, _ = c2.shape
+    if cg != (channels + 7) // 8 or c1.shape != c2.shape or c1_dst.shape != c2.shape or tuple(out.shape) != (B, 11, H, W, 8):
+        raise ValueError("c1, c2, c1_dst must be [B,%d,H,W,8] and out [B,11,H,W,8]" % ((channels + 7) // 8))
+    if H % 2 or W % 2 or tuple(flow32.shape) != (B, 1, H // 2, W // 2, 8) or feat_phases.shape != flow32.shape \
+            or tuple(flow_group.shape) != (B, 1, H, W, 8):
+        raise ValueError("flow32 / feat_phases must be [B,1,H/2,W/2,8] and flow_group [B,1,H,W,8]")
+    for t, n, shp in ((deconv_w, "deconv_w", (2, 2, 4, 4)), (deconv_b, "deconv_b", (2,))):
+        if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous() or t.device != c2.device:
+            raise ValueError("%s must be contiguous float32 %s on %s" % (n, shp, c2.device))
+    strides = [_c8_bstride(t, n, dt) for t, n, dt in (
+        (c1, "c1", torch.float16), (c2, "c2", torch.float16), (flow32, "flow32", torch.float32),
+        (feat_phases, "feat_phases", torch.float32), (c1_dst, "c1_dst", torch.float16),
+        (flow_group, "flow_group", torch.float16), (out, "out", torch.float16))]
+    flags = (_lib.FLAG_CORR_NORMALIZE if normalize else 0) | (FLAG_ACT_LEAKY if leaky_slope is not None else 0)
+    with torch.cuda.device(c2.device):
+        rc = lib.pwc_level_corr81_c8_f16(c1.data_ptr(), c2.data_ptr(), flow32.data_ptr(), feat_phases.data_ptr(),
+                                         deconv_w.data_ptr(), deconv_b.data_ptr(),
+                                         c1_dst.data_ptr(), flow_group.data_ptr(), out.data_ptr(), B, channels, H, W,
+                                         float(flow_scale), 1 if align_corners else 0, float(mask_threshold),
+                                         float(corr_multiply), flags, float(leaky_slope or 0.0), *strides, _stream(c2))
+    check(rc, "pwc_level_corr81_c8_f16")
+    return out
+
+
 def image_conv_s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, leaky_slope: float = 0.1,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv1a (Conv2d(3,16,3,stride 2,pad 1) + LeakyReLU) from a float32 [B,3,H,W] image (dense planes, free batch

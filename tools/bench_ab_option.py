@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of one pwc_set_option switch on the whole forward, interleaved rounds in ONE process (cdna guide rule 24):
-    python tools/bench_ab_option.py <option> <value A> <value B> [batches, default 1,4,16]
+    python tools/bench_ab_option.py <option> <value A> <value B> [batches, default 1,4,16]      (PWC_AB_PRECISION=fp16|fp16-strict: that plan)
 The option is read when a plan is built, so each arm gets its own network, built under its value."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ for B in batches:
     arms = {}
     for v in (va, vb):
         _lib.set_option(opt, v)
-        net = PWCDCNet(use_graph=True).to(dev).eval()
+        net = PWCDCNet(use_graph=True, precision=os.environ.get("PWC_AB_PRECISION", "fp32")).to(dev).eval()
         net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
         x = net.graph_input(B, 448, 1024, dev)
         x.copy_(torch.rand(B, 6, 448, 1024, generator=torch.Generator().manual_seed(1234)))
