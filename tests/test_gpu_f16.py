@@ -683,3 +683,23 @@ def test_level_entry_correlation_fused_equals_two_calls(dev, B, C, H, W):
     with pytest.raises(Exception):
         F16.level_entry_correlation(c1[:, :, :H - 1], c2[:, :, :H - 1], head[:, 0:1], head[:, 1:2], dw, db, C, c1_dst=again[:, 12:12 + g, :H - 1],
                                     flow_group=again[:, 12 + g:13 + g, :H - 1], out=again[:, 1:12, :H - 1])
+
+
+@pytest.mark.parametrize("precision", ["fp16", "fp16-strict"])
+def test_forward_fp16_fused_level_entry_same_bits(dev, precision):
+    """Option f16_level_corr: the half-precision plans enter every level below the coarsest through pwc_level_corr81_c8_f16 (one
+    kernel) instead of level entry + correlation -- the forward's flow must not change by a bit."""
+    from opticalflow_amd import PWCDCNet, _lib
+    from opticalflow_amd.weights import synthetic_state_dict
+    x = torch.rand(2, 6, 192, 320, generator=torch.Generator().manual_seed(21)).to(dev)
+    flows = []
+    for v in (0, 1):
+        _lib.set_option("f16_level_corr", v)
+        try:
+            net = PWCDCNet(precision=precision).to(dev).eval()
+            net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
+            with torch.no_grad():
+                flows.append(net(x).clone())
+        finally:
+            _lib.set_option("f16_level_corr", 0)
+    assert torch.isfinite(flows[0]).all() and torch.equal(flows[0], flows[1])
