@@ -9,7 +9,11 @@
 // reduction over Cin is split across the 8 or 16 waves of the workgroup (wave w takes channels w, w+waves, ...), which
 // all cover the SAME 8x8 pixel tile; partial sums meet in LDS.  That keeps ~600-channel upfeat layers from
 // being one long serial loop per thread (the first version ran 300 us per call regardless of level).
-// Weights are wave-uniform: one lane-per-weight vector load per channel, broadcast by v_readlane.  fp32 only.
+// Weights are wave-uniform (scalar loads).  fp32 only.
+// Small levels (a single pair: 2-112 workgroups) take 21-26 us per launch whatever the level: that is VALU ISSUE on the few CUs that
+// hold the whole Cin x 64-pixel product (16 waves x ~35 channels x ~90 instructions on one CU), not latency -- round 4 measured
+// deeper load pipelines (two / three channels per trip: 24-30 us) and lane-per-weight vector loads + v_readlane (28-33 us), both
+// slower; what would help is more CUs per pixel tile (channel slices in separate workgroups + a deterministic combine).
 #include "pwc_common.h"
 
 namespace pwc_conv {
@@ -61,16 +65,17 @@ deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, con
 #pragma unroll
     for (int co = 0; co < CO; ++co) acc[co][0][0] = acc[co][0][1] = acc[co][1][0] = acc[co][1][1] = 0.f;
 
-    // one channel: its 3x3 neighbourhood times the channel's CO x 16 weights.  The weights are wave-uniform; as scalar loads they
-    // were the kernel's critical path (a scalar-cache miss per channel, 35 channels in a row per wave: 22-26 us per launch at
-    // every level of a single pair, more loads in flight changed nothing).  Now lane j < 32 fetches weight j with the SAME kind of
-    // load as the pixels -- one more vector load in the batch -- and v_readlane broadcasts each one into the fma that uses it.
-    static_assert(CO * 16 <= 64, "a channel's weights fit one wave-wide load");
-    auto channel = [&](const float (&v)[3][3], float wl) {
-        const int wbits = __builtin_bit_cast(int, wl);
+    for (int ci = wave; ci < Cin; ci += kDWaves) {
+        const float *xp = xb + (int64_t)ci * plane;
+        float v[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[a][c] = xp[off[a][c]] * msk[a][c];
+        const float *wc = w + (int64_t)ci * CO * 16;          // wave-uniform
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
-            auto k = [&](int idx) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(wbits, co * 16 + idx)); };   // k[ky*4 + kx]
+            const float *k = wc + co * 16;                    // k[ky*4 + kx]
 #pragma unroll
             for (int py = 0; py < 2; ++py)
 #pragma unroll
@@ -78,36 +83,13 @@ deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, con
                     const int kya = py ? 2 : 3, kyb = py ? 0 : 1;       // rows v[py], v[py+1]
                     const int kxa = px ? 2 : 3, kxb = px ? 0 : 1;       // cols v[.][px], v[.][px+1]
                     float s = acc[co][py][px];
-                    s = fmaf(v[py][px], k(kya * 4 + kxa), s);
-                    s = fmaf(v[py][px + 1], k(kya * 4 + kxb), s);
-                    s = fmaf(v[py + 1][px], k(kyb * 4 + kxa), s);
-                    s = fmaf(v[py + 1][px + 1], k(kyb * 4 + kxb), s);
+                    s = fmaf(v[py][px], k[kya * 4 + kxa], s);
+                    s = fmaf(v[py][px + 1], k[kya * 4 + kxb], s);
+                    s = fmaf(v[py + 1][px], k[kyb * 4 + kxa], s);
+                    s = fmaf(v[py + 1][px + 1], k[kyb * 4 + kxb], s);
                     acc[co][py][px] = s;
                 }
         }
-    };
-    const int wlane = lane & (CO * 16 - 1);
-    auto fetch = [&](int ci, float (&v)[3][3], float &wl) {
-        const float *xp = xb + (int64_t)ci * plane;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[a][c] = xp[off[a][c]] * msk[a][c];
-        wl = w[(int64_t)ci * CO * 16 + wlane];
-    };
-    constexpr int kU = 2;                       // channels per trip: 20 loads in flight (three spill at the 128-register cap of the 16-wave form: 64-bit addresses)
-    int ci = wave;
-    for (; ci + (kU - 1) * kDWaves < Cin; ci += kU * kDWaves) {
-        float v[kU][3][3], wl[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) fetch(ci + u * kDWaves, v[u], wl[u]);
-#pragma unroll
-        for (int u = 0; u < kU; ++u) channel(v[u], wl[u]);
-    }
-    for (; ci < Cin; ci += kDWaves) {
-        float v[3][3], wl;
-        fetch(ci, v, wl);
-        channel(v, wl);
     }
 #pragma unroll
     for (int co = 0; co < CO; ++co)
