@@ -72,6 +72,8 @@ const char *pwc_last_error(void);
  *   "corr_pipe_min_tiles" [PWC_CORR_PIPE_MIN_TILES] 1024 (8x32 tiles a launch needs for the round-4 kernels),
  *   "corr_small_tiles" [PWC_CORR_SMALL_TILES] 48 (launches of at most this many 8x32 tiles use the small-map correlation kernel, and
  *   pwc_warp_corr81_preferred sends them to pwc_warp_fwd + pwc_corr_fwd; 0: the tiled kernels always),
+ *   "head10" [PWC_HEAD10] 1 (fp32 plans: levels too small for pwc_head_upfeat_fwd run predict_flowL + upfeatL as one 10-channel
+ *   convolution followed by pwc_upsample_entry_f32; 0: pwc_conv2d_fwd + two pwc_deconv4x4s2_fwd),
  *   "f16_level_corr" [PWC_F16_LEVEL_CORR] 0 (1: the half-precision plans enter a level through pwc_level_corr81_c8_f16 instead of the two
  *   calls it fuses -- same bits, measured slower at batch 16),
  *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off).
@@ -316,6 +318,13 @@ int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bias, void *y,
                         int B, int Cin, int H, int W, int Cout, int dtype,
                         int64_t x_bstride, int64_t y_bstride,
                         void *stream);
+/* Small levels (ABI v11): the host runs predict_flowL and upfeatL as ONE 3x3 convolution with 10 output channels -- ConvTranspose2d
+ * (k4, s2, p1) is a 3x3 convolution with four output phases per channel -- through pwc_conv2d_fwd (matrix cores, split-K over the
+ * chip) instead of pwc_deconv4x4s2_fwd, which is VALU-bound on the few CUs a small map gives it.  This is the level's exit:
+ * head [B,10,h,w] = [flow u, v | upfeat phases co*4 + py*2 + px] -> out [B,4,2h,2w] = [deconvL(flow) | up_feat] (PWCNet.py:208-209,
+ * 222-223, 236-237, 252-253); deconv_w [2,2,4,4], deconv_b [2] = deconvL's nn.ConvTranspose2d parameters.  Batch strides in elements. */
+int pwc_upsample_entry_f32(const void *head, const void *deconv_w, const void *deconv_b, void *out, int B, int h, int w,
+                           int64_t head_bstride, int64_t out_bstride, void *stream);
 
 /* predict_flowL (Conv2d Cin->2, 3x3) and upfeatL (ConvTranspose2d Cin->2, k4 s2 p1) in ONE pass over x:
  * both read the same 3x3 window of the same [B,Cin,H,W] arena (PWCNet.py:207+209, 221+223, 235+237, 251+253).

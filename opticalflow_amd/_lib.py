@@ -85,6 +85,7 @@ SIGNATURES = {
     "pwc_level_corr81_c8_f16": (c_int, [c_void_p] * 9 + [c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_float, c_uint, c_float]
                                 + [c_int64] * 7 + [c_void_p]),
     "pwc_calib_lds_dma_read": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "pwc_upsample_entry_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_deconv4x4s2_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_head_upfeat_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

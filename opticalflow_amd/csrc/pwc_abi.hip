@@ -41,6 +41,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"corr_pipe_min_tiles", "PWC_CORR_PIPE_MIN_TILES", 1024},
     {"corr_roll", "PWC_CORR_ROLL", 1},                    // C <= 32: the rolling form (a workgroup walks down a column of tiles and keeps its in2 rows)
     {"corr_small_tiles", "PWC_CORR_SMALL_TILES", 48},     // launches of at most this many 8x32 tiles: the small-map correlation (and warp, then correlation, instead of the fused kernel)
+    {"head10", "PWC_HEAD10", 1},                          // small levels: flow head + upfeat as one 10-channel convolution + pwc_upsample_entry_f32 (read by the Python engine)
     {"f16_level_corr", "PWC_F16_LEVEL_CORR", 0},          // half-precision plans: level entry + warp + correlation as one kernel (read by the Python engine);
                                                           // bit-identical, but 97 vs 81 us at level 2 (2.5x halo gathers): opt-in
     {"warpcorr_window", "PWC_WARPCORR_WINDOW", 1},        // fused warp+correlation on the LDS-window kernel: 1 = C <= 32 (level 2), 2 = also C <= 64, 0 = round-2 kernel

@@ -108,6 +108,50 @@ deconv4x4s2_kernel(const float *__restrict__ x, const float *__restrict__ w, con
     }
 }
 
+// ---- small levels: predict_flowL and upfeatL as ONE 10-channel 3x3 convolution, finished here -------------------------------------
+// deconv4x4s2_kernel above is VALU-issue bound on the few CUs a small map gives it (21-26 us per launch).  The host plan instead runs
+// ConvTranspose2d(k4, s2, p1) as what it is -- a 3x3 convolution with four output phases per channel -- together with the flow head
+// on the matrix cores (pwc_conv2d_fwd, split-K over the whole chip): `head` = [flow u, v | upfeat phases co*4 + py*2 + px].  This
+// kernel is the rest of the level's exit (PWCNet.py:208-209 ...): up_flow = deconvL(flow) (2 -> 2 channels: 2x2 input pixels x 2
+// channels per output, fp32) and up_feat = the pixel shuffle of the phases, one thread per output pixel, four channels written.
+__global__ void __launch_bounds__(256)
+upsample_entry_kernel(const float *__restrict__ head, const float *__restrict__ dw, const float *__restrict__ db,
+                      float *__restrict__ out, int h, int w, int64_t npix, int64_t bsh, int64_t bso) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const int H = 2 * h, W = 2 * w;
+    const int64_t plane = (int64_t)H * W, ip = (int64_t)h * w;
+    const int b = (int)(i / plane);
+    const int pix = (int)(i - (int64_t)b * plane);
+    const int yy = pix / W, xx = pix - yy * W;
+    const int py = yy & 1, px = xx & 1;
+    // output row 2Y+py takes input rows r0 = Y-1+py (kernel row 3-py) and r0+1 (kernel row 1-py); same along x
+    const int r0 = (yy >> 1) - 1 + py, c0 = (xx >> 1) - 1 + px;
+    const float *hb = head + (int64_t)b * bsh;
+    float acc0 = db[0], acc1 = db[1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int r = r0 + a, ky = 3 - py - 2 * a;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int cc = c0 + c, kx = 3 - px - 2 * c;
+            if (r < 0 || r >= h || cc < 0 || cc >= w) continue;
+            const float fu = hb[(int64_t)r * w + cc], fv = hb[ip + (int64_t)r * w + cc];
+            acc0 = fmaf(fu, dw[(0 * 2 + 0) * 16 + ky * 4 + kx], acc0);          // dw[ci][co][ky][kx]
+            acc0 = fmaf(fv, dw[(1 * 2 + 0) * 16 + ky * 4 + kx], acc0);
+            acc1 = fmaf(fu, dw[(0 * 2 + 1) * 16 + ky * 4 + kx], acc1);
+            acc1 = fmaf(fv, dw[(1 * 2 + 1) * 16 + ky * 4 + kx], acc1);
+        }
+    }
+    const int64_t sp = (int64_t)(yy >> 1) * w + (xx >> 1);
+    const int ph = py * 2 + px;
+    float *ob = out + (int64_t)b * bso + pix;
+    ob[0] = acc0;
+    ob[plane] = acc1;
+    ob[2 * plane] = hb[(2 + ph) * ip + sp];
+    ob[3 * plane] = hb[(6 + ph) * ip + sp];
+}
+
 }  // namespace
 
 extern "C" int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bias, void *y,
@@ -137,4 +181,21 @@ extern "C" int pwc_deconv4x4s2_fwd(const void *x, const void *w, const void *bia
                            static_cast<const float *>(x), static_cast<const float *>(w), static_cast<const float *>(bias),
                            static_cast<float *>(y), Cin, H, W, tiles_x, tiles_y, x_bstride, y_bstride);
     return pwc::check_launch("deconv4x4s2_kernel");
+}
+
+/* Exit of a decoder level whose flow head and upfeatL ran as one 10-channel 3x3 convolution (models/PWCNet.py:207-209, 221-223 ...):
+ * head [B,10,h,w] = [flow (2) | upfeat phases co*4 + py*2 + px (8)]; out [B,4,2h,2w] = [deconvL(flow) (2) | up_feat (2)], the four
+ * channels the next level's arena holds behind c1.  deconv_w [2,2,4,4] / deconv_b [2]: nn.ConvTranspose2d(2,2,4,2,1) of deconvL. */
+extern "C" int pwc_upsample_entry_f32(const void *head, const void *deconv_w, const void *deconv_b, void *out, int B, int h, int w,
+                                      int64_t head_bstride, int64_t out_bstride, void *stream) {
+    if (!head || !deconv_w || !deconv_b || !out) PWC_FAIL(PWC_EINVAL, "pwc_upsample_entry_f32: null pointer");
+    if (B <= 0 || h <= 0 || w <= 0) PWC_FAIL(PWC_EINVAL, "pwc_upsample_entry_f32: bad shape");
+    if (head_bstride < (int64_t)10 * h * w || out_bstride < (int64_t)16 * h * w)
+        PWC_FAIL(PWC_EINVAL, "pwc_upsample_entry_f32: batch stride smaller than the tensor");
+    const int64_t npix = (int64_t)B * 4 * h * w;
+    if ((npix + 255) / 256 > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_upsample_entry_f32: grid too large");
+    hipLaunchKernelGGL(upsample_entry_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(head), static_cast<const float *>(deconv_w), static_cast<const float *>(deconv_b),
+                       static_cast<float *>(out), h, w, npix, head_bstride, out_bstride);
+    return pwc::check_launch("upsample_entry_kernel");
 }

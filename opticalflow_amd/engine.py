@@ -127,6 +127,16 @@ class PwcPlan:
             self.arena_base[l] = DENSE_TOTAL if (l > 2 or trunk2) else 0
             self.arena[l] = torch.empty((B, self.arena_base[l] + od, *self.size[l]), **kw)
         self.flow = {l: torch.empty((B, 2, *self.size[l]), **kw) for l in range(2 if trunk2 else 3, 7)}
+        # Levels too small for the streaming head + upfeat kernel (W < 64: levels 6-5; all of 6-3 for a single pair): predict_flowL and
+        # upfeatL run as ONE 3x3 convolution with 10 output channels on the matrix cores (ConvTranspose2d(k4,s2,p1) = a 3x3 convolution
+        # with four output phases per channel) and ops.upsample_entry finishes the level -- the VALU deconvolution kernel took 21-26 us
+        # per launch there.  flow[l] is then channels 0,1 of that convolution's output.
+        self.head10: Dict[int, torch.Tensor] = {}
+        if conv_backend == "hip" and _lib.get_option("head10"):
+            for l in range(3, 7):
+                if not ops.head_upfeat_supported(B, *self.size[l]):
+                    self.head10[l] = torch.empty((B, 10, *self.size[l]), **kw)
+                    self.flow[l] = self.head10[l][:, 0:2]
         h2, w2 = self.size[2]
         self.flow_out = torch.empty((B, 2, h2, w2), **kw) if trunk2 else None
         self.ctx = [torch.empty((B, c, h2, w2), **kw) for c, _ in CONTEXT] if trunk2 else []
@@ -168,6 +178,12 @@ class PwcPlan:
                     # G g Gt for every layer the Winograd route could take (67 MB for the whole net): nothing is allocated later
                     if self.wino and t.shape[0] >= 32 and t.shape[1] >= 16:
                         self.wino_packed[key[:-len(".weight")]] = ops.pack_conv3x3_wino(t)
+            for l in self.head10:
+                w10 = torch.cat((self.p["predict_flow%d.weight" % l], ops.deconv_as_conv3x3(self.p["upfeat%d.weight" % l])), 0)
+                self.p["head10_%d.weight" % l] = w10.contiguous()
+                self.p["head10_%d.bias" % l] = torch.cat((self.p["predict_flow%d.bias" % l],
+                                                           self.p["upfeat%d.bias" % l].repeat_interleave(4))).contiguous()
+                self.packed["head10_%d" % l] = ops.pack_conv3x3(self.p["head10_%d.weight" % l])
             # F(4x4,3x3) banks for the layers the measured rule picks at THIS geometry (4x the filter bytes each): packed now, so that a
             # run never allocates (the lazy path in _conv only serves callers that drive _conv with other shapes, e.g. bench probes)
             if self.wino and self.wino4:
@@ -222,10 +238,10 @@ class PwcPlan:
         for l in range(2 if trunk2 else 3, 7):                 # dense blocks + flow heads
             h, w = self.size[l]
             cin = level_in_channels(l, self.nd)
-            for co in DENSE_OUT + (2,):
+            for co in DENSE_OUT + (2, 10):                     # 10: flow head + upfeat phases as one convolution (small levels)
                 out.append((B, cin, h, w, co, 1))
                 out.append((B, cin, h, w, min(co, 64), 1))     # the F(4x4) part of a 96-cout layer run as 64 + 32
-                cin += co if co != 2 else 0
+                cin += co if co not in (2, 10) else 0
         if trunk2:
             h, w = self.size[2]
             cin = level_in_channels(2, self.nd) + DENSE_TOTAL
@@ -415,6 +431,10 @@ class PwcPlan:
         cn = PYRAMID_CH[l - 1]
         o = self.arena_base[l - 1] + self.nd + cn
         h, w = self.size[l]
+        if l in self.head10:
+            self._conv("head10_%d" % l, ar, self.head10[l], act=False)
+            ops.upsample_entry(self.head10[l], self.p["deconv%d.weight" % l], self.p["deconv%d.bias" % l], nxt[:, o:o + 4])
+            return
         if self.conv_backend == "hip" and ops.head_upfeat_supported(self.B, h, w):
             # predict_flowL and upfeatL read the same 3x3 windows of the same arena: one pass
             ops.head_upfeat(ar, self.packed["predict_flow%d" % l], self.p["predict_flow%d.bias" % l],

@@ -49,19 +49,7 @@ def _pad_cin(w: torch.Tensor, phys: int) -> torch.Tensor:
     return out
 
 
-def _deconv_as_conv3x3(wt: torch.Tensor) -> torch.Tensor:
-    """ConvTranspose2d(k4, s2, p1) filters [Cin, Cout, 4, 4] -> 3x3 conv filters [Cout*4, Cin, 3, 3], output channel
-    co*4 + py*2 + px = phase (py, px) of output pixel (2*iy+py, 2*ix+px):
-    py = 0 takes window rows a = 0, 1 with ky = 3, 1;  py = 1 takes a = 1, 2 with ky = 2, 0  (same along x)."""
-    cin, cout = wt.shape[:2]
-    k = wt.new_zeros((cout, 2, 2, cin, 3, 3))
-    taps = {0: ((0, 3), (1, 1)), 1: ((1, 2), (2, 0))}          # phase -> ((window index, kernel index), ...)
-    for py in (0, 1):
-        for a, ky in taps[py]:
-            for px in (0, 1):
-                for e, kx in taps[px]:
-                    k[:, py, px, :, a, e] = wt[:, :, ky, kx].t()
-    return k.reshape(cout * 4, cin, 3, 3)
+_deconv_as_conv3x3 = ops.deconv_as_conv3x3     # ConvTranspose2d(k4, s2, p1) as a 3x3 convolution with four output phases per channel
 
 
 def _phys_index(level: int, nd: int = 81) -> torch.Tensor:

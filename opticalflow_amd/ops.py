@@ -501,6 +501,38 @@ def head_upfeat(x: torch.Tensor, head_wpacked: torch.Tensor, head_bias: torch.Te
     check(rc, "pwc_head_upfeat_fwd")
 
 
+def deconv_as_conv3x3(wt: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(k4, s2, p1) filters [Cin, Cout, 4, 4] -> 3x3 conv filters [Cout*4, Cin, 3, 3], output channel
+    co*4 + py*2 + px = phase (py, px) of output pixel (2*iy+py, 2*ix+px):
+    py = 0 takes window rows a = 0, 1 with ky = 3, 1;  py = 1 takes a = 1, 2 with ky = 2, 0  (same along x)."""
+    cin, cout = wt.shape[:2]
+    k = wt.new_zeros((cout, 2, 2, cin, 3, 3))
+    taps = {0: ((0, 3), (1, 1)), 1: ((1, 2), (2, 0))}          # phase -> ((window index, kernel index), ...)
+    for py in (0, 1):
+        for a, ky in taps[py]:
+            for px in (0, 1):
+                for e, kx in taps[px]:
+                    k[:, py, px, :, a, e] = wt[:, :, ky, kx].t()
+    return k.reshape(cout * 4, cin, 3, 3)
+
+
+def upsample_entry(head: torch.Tensor, deconv_w: torch.Tensor, deconv_b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Exit of a decoder level whose flow head and upfeat ran as one 10-channel 3x3 convolution: head [B,10,h,w] = [flow | upfeat
+    phases] -> out [B,4,2h,2w] = [deconvL(flow) | up_feat] (C-ABI pwc_upsample_entry_f32; PWCNet.py:208-209)."""
+    lib = _lib.load()
+    B, c, h, w = head.shape
+    if c != 10 or head.dtype != torch.float32 or tuple(out.shape) != (B, 4, 2 * h, 2 * w) or out.dtype != torch.float32:
+        raise ValueError("head must be float32 [B,10,h,w] and out [B,4,2h,2w], got %s / %s" % (tuple(head.shape), tuple(out.shape)))
+    for t, n, shp in ((deconv_w, "deconv_w", (2, 2, 4, 4)), (deconv_b, "deconv_b", (2,))):
+        if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_contiguous() or t.device != head.device:
+            raise ValueError("%s must be contiguous float32 %s on %s" % (n, shp, head.device))
+    bsh, bso = _plane_dense(head, "head"), _plane_dense(out, "out")
+    with torch.cuda.device(head.device):
+        rc = lib.pwc_upsample_entry_f32(head.data_ptr(), deconv_w.data_ptr(), deconv_b.data_ptr(), out.data_ptr(), B, h, w, bsh, bso, _stream(head))
+    check(rc, "pwc_upsample_entry_f32")
+    return out
+
+
 def deconv4x4s2(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.ConvTranspose2d(k=4, s=2, p=1); weight [Cin,Cout,4,4] float32 contiguous."""

@@ -1456,3 +1456,40 @@ def test_corr_small_map_kernel(gpu_device, shape):
     assert d <= tol, d
     norm = ops.correlation(ad, bd, 4, 1, 4, 1, 1, 1.0, normalize=True)
     assert (norm.cpu() - O.correlation(a, b, 4, 1, 4, 1, 1, 1) / C).abs().max().item() <= tol / C
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 529, 7, 16), (16, 597, 14, 32), (2, 213, 9, 11), (1, 565, 56, 128)])
+def test_head10_conv_and_upsample_entry_vs_fp64(gpu_device, case):
+    """Small levels: predict_flowL and upfeatL as ONE 3x3 convolution with 10 output channels (ConvTranspose2d(k4,s2,p1) = a 3x3
+    convolution with four output phases per channel, ops.deconv_as_conv3x3) on the matrix cores, finished by pwc_upsample_entry_f32
+    (deconvL of the flow + pixel shuffle of the phases into the next level's four arena channels).  Against torch's fp64 conv2d /
+    conv_transpose2d (PWCNet.py:207-209), arena-strided output, odd sizes; the whole-forward goldens cover it end to end."""
+    from opticalflow_amd import ops
+    B, cin, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, h, w, generator=g)
+    wf = torch.randn(2, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bf = torch.randn(2, generator=g) * 0.1
+    wu = torch.randn(cin, 2, 4, 4, generator=g) * (2.0 / (cin * 4)) ** 0.5
+    bu = torch.randn(2, generator=g) * 0.1
+    wd = torch.randn(2, 2, 4, 4, generator=g) * 0.3
+    bd = torch.randn(2, generator=g) * 0.1
+    dev = gpu_device
+    w10 = torch.cat((wf, ops.deconv_as_conv3x3(wu)), 0).contiguous()
+    b10 = torch.cat((bf, bu.repeat_interleave(4))).contiguous()
+    need = ops.conv3x3_workspace_bytes(B, cin, h, w, 10)
+    ws = torch.empty(max(need, 16) // 4, device=dev)
+    head = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w10.to(dev)), b10.to(dev), 10, leaky_slope=None, workspace=ws)
+    arena = torch.full((B, 9, 2 * h, 2 * w), 7.0, device=dev)
+    ops.upsample_entry(head, wd.to(dev), bd.to(dev), arena[:, 3:7])
+    assert (arena[:, :3] == 7).all() and (arena[:, 7:] == 7).all()
+    flow = F.conv2d(x.double(), wf.double(), bf.double(), padding=1)
+    up_flow = F.conv_transpose2d(flow, wd.double(), bd.double(), stride=2, padding=1)
+    up_feat = F.conv_transpose2d(x.double(), wu.double(), bu.double(), stride=2, padding=1)
+    tol = 3e-6 * (cin * 9) ** 0.5
+    assert (head[:, 0:2].cpu().double() - flow).abs().max().item() <= tol
+    assert (arena[:, 3:5].cpu().double() - up_flow).abs().max().item() <= 4 * tol
+    assert (arena[:, 5:7].cpu().double() - up_feat).abs().max().item() <= tol
+    with pytest.raises(ValueError):
+        ops.upsample_entry(head[:, :9], wd.to(dev), bd.to(dev), arena[:, 3:7])
