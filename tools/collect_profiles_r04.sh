@@ -37,6 +37,7 @@ PWC_BENCH_LEVELS=2,3 python3 "$ROOT/tools/bench_corr_pipe.py" time plan > "$OUT/
 PWC_BENCH_LEVELS=2 rocprofv3 --kernel-trace --stats -d "$OUT/p2" -o p --output-format csv -- python3 "$ROOT/tools/bench_corr_pipe.py" time plan > /dev/null 2>&1
 cp "$(find "$OUT/p2" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_warpcorr.csv"; rm -rf "$OUT/p2"
 python3 "$ROOT/tools/bench_warpcorr.py" > "$OUT/microbench_warpcorr.txt" 2>&1
+make -s -C "$ROOT/tools/experiments/ubench" > /dev/null 2>&1
 "$ROOT/tools/experiments/ubench/rw_mix" > "$OUT/ubench_rw_mix.txt" 2>&1
 "$ROOT/tools/experiments/ubench/valu_rate" > "$OUT/ubench_valu_rate.txt" 2>&1
 fi
