@@ -1,4 +1,4 @@
-// Cost-volume correlation for gfx950, round-4 form: ONE workgroup per CU, a deep LDS-DMA ring, the output drained through LDS.
+// Cost-volume correlation for gfx950, round-4 form: ONE workgroup per CU, a deep LDS-DMA ring, the output leaving plane by plane.
 //
 // Same operator and tile roles as corr81_dma_kernel in pwc_corr.hip (reference semantics: correlation_cuda_kernel.cu:73-147 /
 // correlation.py:12-40; PWC configuration pad 4, kernel 1, max displacement 4, strides 1; fused form PWCNet.py:141-177,212-214):
@@ -16,10 +16,11 @@
 //     as their fmas (a wave issues in order).
 // Hence:
 //   * ONE workgroup per CU, ring of R = 8 chunks: two loader waves keep six chunks (90 KB, ~50 KB of them HBM bytes) in flight.
-//   * THE OUTPUT NEVER LEAVES FROM THE FMA WAVES.  A finished tile's 36 values per lane move to a second register set
-//     (finalised: scale, LeakyReLU); during the NEXT tile's ring steps the fma waves drop them piecewise (81 planes spread
-//     evenly over the steps) into a small double-buffered LDS stage, and a DRAINER wave reads the stage back and issues the
-//     16-byte stores: ~10 store instructions per ring step, never a burst, from a wave whose stalls stop nobody's arithmetic.
+//   * THE OUTPUT NEVER LEAVES AS A BURST.  A finished tile's 36 values per lane move to a second register set (finalised: scale,
+//     LeakyReLU); during the NEXT tile's ring steps each fma wave stores them plane by plane (81 planes spread evenly over the
+//     steps: about one 16-byte store instruction per wave and step, behind its fmas).  The first form dropped them into a small
+//     double-buffered LDS stage that a DRAINER wave read back and stored (VERDICT r3's proposal): 68.7 us against 67.1 us for the
+//     direct stores -- one wave issuing ten stores per step pays 80 cycles for each, in order -- so the stage went.
 //   * Every step is STATIC code: the kernel is a template of the chunk count (8: level 2, 16: level 3), the tile loop's body is
 //     the unrolled sequence of its steps -- ring slot, stage share and plane numbers are immediates; the fma waves execute
 //     ~10 scalar instructions per step.
@@ -40,7 +41,8 @@
                             // 16 = every batch item is written over item 0 (cache-resident output), 32 = every batch item reads item 0,
                             // 64 = default-policy stores instead of nt, 128 = sc0 sc1 (write-through) stores, 256 = only half of the in2 rows are fetched, 512 = in1 is not fetched,
                             // 1024 = in1 is read as 1 KB contiguous per channel and tile, 2048 = (fused) every pixel takes the gather path,
-                            // 4096 = (fused) the producers only keep the barriers
+                            // 4096 = (fused) the producers only keep the barriers, 8192 = (fused) no pixel ever counts as outside the window,
+                            // 16384 = (fused) the outside pixels' gathers are neither issued nor blended, 32768 = issued, not blended
 #endif
 
 namespace {
@@ -656,10 +658,19 @@ constexpr int kWMy = 3, kWMx = 4;                             // margins (rows /
 constexpr int kWinF = kCK * kWR * kWC;                        // 4784 floats per ring slot
 constexpr int kWinI = (kCK * kWR * kWQ + 63) / 64;            // 19 LDS-DMA instructions per chunk (the last one partly out of range)
 constexpr int kWinSlots = 4, kS2Slots = 4;
-constexpr int kProducers = 4, kProdPx = 3;                    // 4 x 64 x 3 = 768 >= 640 halo pixels
+// Sixteen waves is all a workgroup gets, and the producers' chain per ring step is the kernel's critical path: the in1 stream (five
+// LDS-DMA instructions per step) rides on the second window loader wave, which frees a wave for a FIFTH producer -- two halo
+// pixels per lane instead of three (5 x 64 x 2 = 640 exactly): 104.9 -> 100.0 us on one box.  PWC_PIPE_PROD4 = the first form
+// (own in1 loader wave, 4 x 3 pixels).
+#ifdef PWC_PIPE_PROD4
+constexpr int kProducers = 4, kProdPx = 3, kLoaderWaves = 3;  // 4 x 64 x 3 = 768 >= 640 halo pixels
+#else
+constexpr int kProducers = 5, kProdPx = 2, kLoaderWaves = 2;
+#endif
 static_assert(kProducers * 64 * kProdPx >= kS2Rows * kPitch, "halo pixels");
-constexpr int kWaveWin0 = kND + 1, kWaveProd0 = kND + 3;      // waves: 0-8 fma, 9 in1 loader, 10-11 window loaders, 12-15 producers
-constexpr int kThreadsWarp = 64 * (kND + 3 + kProducers);     // 1024: four waves per SIMD, 128 registers
+constexpr int kWaveWin0 = kND + kLoaderWaves - 2, kWaveProd0 = kND + kLoaderWaves;    // waves: 0-8 fma, [9 in1 loader,] two window loaders, producers
+constexpr int kThreadsWarp = 64 * (kND + kLoaderWaves + kProducers);     // 1024: four waves per SIMD, 128 registers
+static_assert(kThreadsWarp == 1024, "sixteen waves");
 constexpr int kLdsWarp = (kR * kS1F + kS2Slots * kS2F + kWinSlots * kWinF) * 4;
 static_assert(kLdsWarp <= 160 * 1024, "LDS");
 static_assert(kWR == kS2Rows + 2 * kWMy + 1 && kWC >= kPitch + 2 * kWMx + 1 + 3, "window covers the halo tile + margins + tap + alignment");
@@ -788,6 +799,58 @@ __device__ __forceinline__ void in1_loader_wave(const PipeArgs &a, float *s1ring
     for (int t = 0; t < my_tiles; ++t) in1_loader_steps<NCH, 0>(ld, a, s1ring, lane, plane, t, nsteps, stride);
 }
 
+// ---- window loader 1 + in1 loader in ONE wave ------------------------------------------------------------------------
+// Per step, in issue order: in1 chunk s+kR-1 (kS1I instructions), then window chunk s+4 (I).  vmcnt retires in order, so "window
+// chunk s+3 has landed" = at most the kS1I + I instructions issued after it are still in flight -- and every in1 chunk the fma
+// waves can want (issued six steps earlier) has landed with it.
+template <int NCH, int K>
+__device__ __forceinline__ void win_in1_loader_steps(WinLoader<1> &lw, Loader<0, kS1I> &l1, const PipeArgs &a, float *s1ring, float *win,
+                                                     int lane, int plane, int t, int nsteps, int stride) {
+    if constexpr (K < NCH) {
+        constexpr int I = WinLoader<1>::I;
+        const int s = t * NCH + K;
+        constexpr int kc1 = (K + kR - 1) % NCH, kcw = (K + kWinSlots) % NCH;
+        const bool go1 = s + kR - 1 < nsteps && !(PWC_PIPE_EXP & 4), gow = s + kWinSlots < nsteps && !(PWC_PIPE_EXP & 4);
+        if (go1) {
+            if constexpr (kc1 == 0) l1.new_tile(a, (int)blockIdx.x + (t + (K + kR - 1) / NCH) * stride, lane, plane);
+            l1.issue(a, kc1, (K + kR - 1) % kR, s1ring, nullptr, plane);
+        }
+        if (gow) {
+            if constexpr (kcw == 0) lw.new_tile(a, (int)blockIdx.x + (t + (K + kWinSlots) / NCH) * stride, lane, plane);
+            lw.issue(a, kcw, K % kWinSlots, win, plane);
+        }
+        if (go1)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kS1I + I) : "memory");     // (go1 implies gow: kR - 1 > kWinSlots)
+        else if (gow) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(I) : "memory");
+        else          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        win_in1_loader_steps<NCH, K + 1>(lw, l1, a, s1ring, win, lane, plane, t, nsteps, stride);
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void win_in1_loader_wave(const PipeArgs &a, float *s1ring, float *win, int lane, int my_tiles) {
+    constexpr int I = WinLoader<1>::I;
+    static_assert(kR - 1 > kWinSlots && (kR - 1) * kS1I + (kWinSlots - 1) * I <= 63, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_setprio(3);
+    const int plane = a.H * a.W, stride = gridDim.x, nsteps = my_tiles * NCH;
+    WinLoader<1> lw;
+    Loader<0, kS1I> l1;
+    lw.new_tile(a, blockIdx.x, lane, plane);
+    l1.new_tile(a, blockIdx.x, lane, plane);
+#pragma unroll
+    for (int k = 0; k < kR - 1; ++k)
+        if (k < nsteps) l1.issue(a, k, k, s1ring, nullptr, plane);          // in1 chunks 0..6
+#pragma unroll
+    for (int k = 0; k < kWinSlots - 1; ++k) lw.issue(a, k, k, win, plane);   // window chunks 0, 1, 2 (NCH >= 8)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kWinSlots - 1) * I) : "memory");      // the in1 chunks have landed (keeps the counter under 64)
+    lw.issue(a, kWinSlots - 1, kWinSlots - 1, win, plane);                  // window chunk 3
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(I) : "memory");               // window chunks 0, 1, 2 have landed
+    __builtin_amdgcn_s_barrier();                   // B_pre: the producers make the first two in2 chunks
+    __builtin_amdgcn_s_barrier();                   // B_0
+#pragma unroll 1
+    for (int t = 0; t < my_tiles; ++t) win_in1_loader_steps<NCH, 0>(lw, l1, a, s1ring, win, lane, plane, t, nsteps, stride);
+}
+
 // ---- producer waves ---------------------------------------------------------------------------------------------------
 struct ProdPx {                  // one halo pixel of this lane
     int dst;                     // float index inside an in2 chunk image [c][16][40]; < 0: no pixel (slot past the 640)
@@ -830,9 +893,9 @@ __device__ __forceinline__ void prod_setup(ProdPx (&px)[kProdPx], const PipeArgs
         px[k].obot = pt.obot * 4;
         const int rt = pt.otop / a.W, xb = pt.otop - rt * a.W, rb = pt.obot / a.W;
         const int wr = rt - pf.org.wy0, wr2 = rb - pf.org.wy0, wc = xb - pf.org.wx0;
-        const bool inside = (wr >= 0) && (wr2 < kWR) && (wr2 >= wr) && (wc >= 0) && (wc + 1 < kWC) && !(PWC_PIPE_EXP & 2048);
-        px[k].wt = inside ? wr * kWC + wc : -1;
-        px[k].wb = wr2 * kWC + wc;
+        const bool inside = ((wr >= 0) && (wr2 < kWR) && (wr2 >= wr) && (wc >= 0) && (wc + 1 < kWC) && !(PWC_PIPE_EXP & 2048)) || (PWC_PIPE_EXP & 8192);
+        px[k].wt = inside ? ((PWC_PIPE_EXP & 8192) ? min(max(wr, 0), kWR - 2) * kWC + min(max(wc, 0), kWC - 2) : wr * kWC + wc) : -1;
+        px[k].wb = (PWC_PIPE_EXP & 8192) ? px[k].wt + kWC : wr2 * kWC + wc;
         px[k].dst = (hp < kS2Rows * kPitch) ? row * kPitch + col : -1;
     }
 }
@@ -844,7 +907,8 @@ struct ProdState {
 };
 
 // pixels inside the window: two ds_read2_b32 + blend4 + one ds_write_b32 per pixel and channel.  (Requesting the reads of two or
-// three pixels before the first blend was tried: 16 / 32 more live registers next to the gathered taps spill at 128, 123 vs 109 us.)
+// three pixels before the first blend was tried: 16 / 32 more live registers next to the gathered taps spill at 128, 123 vs 109 us;
+// with two pixels per lane nothing spills and nothing is gained: 100.0 vs 100.4 us.)
 __device__ __forceinline__ void prod_sample(const ProdState &ps, float *dst, const float *win) {
 #pragma unroll
     for (int k = 0; k < kProdPx; ++k) {
@@ -872,7 +936,7 @@ __device__ __forceinline__ void prod_gather_issue(ProdState &ps, const PipeArgs 
                                                                   __builtin_amdgcn_readfirstlane(min(kCK, a.C - c0) * plane * 4), 0x00020000);
 #pragma unroll
     for (int k = 0; k < kProdPx; ++k) {
-        const bool out = ps.px[k].dst >= 0 && ps.px[k].wt < 0;
+        const bool out = ps.px[k].dst >= 0 && ps.px[k].wt < 0 && !(PWC_PIPE_EXP & 16384);
         if (__builtin_amdgcn_ballot_w64(out)) {                 // wave-uniform: some pixel of this slot has left the window
             if (out) {
 #pragma unroll
@@ -888,7 +952,7 @@ __device__ __forceinline__ void prod_gather_issue(ProdState &ps, const PipeArgs 
 __device__ __forceinline__ void prod_gather_finish(const ProdState &ps, float *dst) {
 #pragma unroll
     for (int k = 0; k < kProdPx; ++k) {
-        const bool out = ps.px[k].dst >= 0 && ps.px[k].wt < 0;
+        const bool out = ps.px[k].dst >= 0 && ps.px[k].wt < 0 && !(PWC_PIPE_EXP & (16384 | 32768));
         if (__builtin_amdgcn_ballot_w64(out)) {
             if (out) {
 #pragma unroll
@@ -1007,9 +1071,14 @@ warp_corr81_pipe_kernel(PipeArgs a) {
     const int stride = gridDim.x;
     const int my_tiles = (a.nblk - (int)blockIdx.x + stride - 1) / stride;
     // barriers of every wave: B_pre, B_0 and one at the end of every ring step
+#ifdef PWC_PIPE_PROD4
     if (wave == kND)                 in1_loader_wave<NCH>(a, s1ring, lane, my_tiles);
     else if (wave == kWaveWin0)      win_loader_wave<NCH, 0>(a, win, lane, my_tiles);
     else if (wave == kWaveWin0 + 1)  win_loader_wave<NCH, 1>(a, win, lane, my_tiles);
+#else
+    if (wave == kWaveWin0)           win_loader_wave<NCH, 0>(a, win, lane, my_tiles);
+    else if (wave == kWaveWin0 + 1)  win_in1_loader_wave<NCH>(a, s1ring, win, lane, my_tiles);
+#endif
     else if (wave >= kWaveProd0)     producer_wave<NCH>(a, s2ring, win, wave - kWaveProd0, lane, my_tiles);
     else                             warp_fma_wave<NCH>(a, s1ring, s2ring, wave, lane, my_tiles);
 }
