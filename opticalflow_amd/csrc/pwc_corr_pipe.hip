@@ -891,7 +891,8 @@ __device__ __forceinline__ void prod_setup(ProdPx (&px)[kProdPx], const PipeArgs
         px[k].wa = inimg ? pt.wa : 0.f; px[k].wb_ = inimg ? pt.wb : 0.f; px[k].wc = inimg ? pt.wc : 0.f; px[k].wd = inimg ? pt.wd : 0.f;
         px[k].otop = pt.otop * 4;
         px[k].obot = pt.obot * 4;
-        const int rt = pt.otop / a.W, xb = pt.otop - rt * a.W, rb = pt.obot / a.W;
+        const int rt = pt.rtop, xb = pt.xb, rb = pt.rbot;           // (rows and column straight from the taps: four integer divisions per pixel, ~35
+                                                                        //  instructions each, sat here and in make_pair_taps -- 100-103 -> 96.8 us without them)
         const int wr = rt - pf.org.wy0, wr2 = rb - pf.org.wy0, wc = xb - pf.org.wx0;
         const bool inside = ((wr >= 0) && (wr2 < kWR) && (wr2 >= wr) && (wc >= 0) && (wc + 1 < kWC) && !(PWC_PIPE_EXP & 2048)) || (PWC_PIPE_EXP & 8192);
         px[k].wt = inside ? ((PWC_PIPE_EXP & 8192) ? min(max(wr, 0), kWR - 2) * kWC + min(max(wc, 0), kWC - 2) : wr * kWC + wc) : -1;

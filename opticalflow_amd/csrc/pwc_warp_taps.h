@@ -9,6 +9,7 @@ struct Taps {
     int o00, o01, o10, o11;     // element offsets inside a plane (clamped, always valid)
     float w00, w01, w10, w11;   // bilinear weight * in-bounds * mask
     int x0;                     // unclamped column of the left taps (pair loads, see make_pair_taps)
+    int r0, r1;                 // rows of the top / bottom taps (clamped): o00 = r0 * W + ..., o10 = r1 * W + ...
 };
 
 __device__ __forceinline__ Taps make_taps(float px, float py, int H, int W, int align_corners, float thr) {
@@ -46,6 +47,8 @@ __device__ __forceinline__ Taps make_taps(float px, float py, int H, int W, int 
     t.o10 = yc1 * W + xc0;
     t.o11 = yc1 * W + xc1;
     t.x0 = x0;
+    t.r0 = yc0;
+    t.r1 = yc1;
     return t;
 }
 
@@ -55,16 +58,19 @@ __device__ __forceinline__ Taps make_taps(float px, float py, int H, int W, int 
 // position of an exact zero term changes.
 struct PairTaps {
     int otop, obot;             // element offsets of the pairs inside a plane
+    int rtop, rbot, xb;         // the same as rows and first column (no integer division downstream: ~35 instructions each on gfx950)
     float wa, wb, wc, wd;
 };
 
 __device__ __forceinline__ PairTaps make_pair_taps(float px, float py, int H, int W, int align_corners, float thr) {
     const Taps t = make_taps(px, py, H, W, align_corners, thr);
     const int xb = min(max(t.x0, 0), W - 2);
-    const int rtop = t.o00 / W, rbot = t.o10 / W;
     PairTaps p;
-    p.otop = rtop * W + xb;
-    p.obot = rbot * W + xb;
+    p.rtop = t.r0;
+    p.rbot = t.r1;
+    p.xb = xb;
+    p.otop = t.r0 * W + xb;
+    p.obot = t.r1 * W + xb;
     const bool same = (t.x0 == xb), left_edge = (t.x0 + 1 == xb), right_edge = (t.x0 == xb + 1);
     p.wa = same ? t.w00 : (left_edge ? t.w01 : 0.0f);
     p.wb = same ? t.w01 : (right_edge ? t.w00 : 0.0f);
