@@ -107,6 +107,11 @@ __device__ __forceinline__ TileXY tile_of(int t, int nblk, int tiles_x, int tile
     r.b = t / tiles_y;
     return r;
 }
+// the same from the divisors' reciprocals (q = mulhi(t, ceil(2^32 / d)) is exact while t * d < 2^32: fill_magic checks): every wave
+// role calls this once per tile and a runtime integer division is ~35 instructions on gfx950 (measured: no difference here, the
+// divisions were not on the critical path -- kept because it is simply less code to execute)
+struct PipeArgs;
+__device__ __forceinline__ TileXY tile_of(int t, const PipeArgs &a);
 
 template <int I>
 __device__ __forceinline__ void wait_chunks_in_flight(int n) {       // s_waitcnt vmcnt(n * I), n wave-uniform in [0, kR-2]
@@ -133,7 +138,19 @@ struct PipeArgs {
     int64_t bsf;
     float flow_scale, thr;
     int align_corners;
+    unsigned magic_tx, magic_ty;            // ceil(2^32 / tiles_x), ceil(2^32 / tiles_y): tile_of() without integer division (set by fill_magic)
 };
+
+__device__ __forceinline__ TileXY tile_of(int t, const PipeArgs &a) {
+    if ((a.nblk & 7) == 0) t = (t & 7) * (a.nblk >> 3) + (t >> 3);
+    const unsigned q1 = a.tiles_x == 1 ? (unsigned)t : __umulhi((unsigned)t, a.magic_tx);       // (ceil(2^32 / 1) does not fit a word)
+    const unsigned q2 = a.tiles_y == 1 ? q1 : __umulhi(q1, a.magic_ty);
+    TileXY r;
+    r.x0 = (int)((unsigned)t - q1 * (unsigned)a.tiles_x) * kTW;
+    r.y0 = (int)(q1 - q2 * (unsigned)a.tiles_y) * kTH;
+    r.b = (int)q2;
+    return r;
+}
 
 // The 81 output planes of a tile leave during the NCH ring steps of the next one: step K takes the pieces q in
 // [81 K / NCH, 81 (K+1) / NCH), piece q = plane (q % 9) * 9 + q / 9 -- displacement column dx = q / 9 of fma wave q % 9, so that
@@ -284,7 +301,7 @@ __device__ __forceinline__ void set_destination_xy(FmaState<LA> &st, const PipeA
 
 template <int LA>
 __device__ __forceinline__ void set_destination(FmaState<LA> &st, const PipeArgs &a, int tile, int r, int g) {
-    set_destination_xy(st, a, tile_of(tile, a.nblk, a.tiles_x, a.tiles_y), r, g);
+    set_destination_xy(st, a, tile_of(tile, a), r, g);
 }
 
 template <int LA>
@@ -337,7 +354,7 @@ struct Loader {
     const float *ip1, *ip2;
 
     __device__ __forceinline__ void new_tile(const PipeArgs &a, int tile, int lane, int plane) {
-        const TileXY t = tile_of(tile, a.nblk, a.tiles_x, a.tiles_y);
+        const TileXY t = tile_of(tile, a);
 #pragma unroll
         for (int k = K0; k < K1; ++k) {
             int c, row, q, iy, ix;
@@ -709,7 +726,7 @@ struct WinLoader {
     unsigned off[I];
     const float *ip;
     __device__ __forceinline__ void new_tile(const PipeArgs &a, int tile, int lane, int plane) {
-        const TileXY t = tile_of(tile, a.nblk, a.tiles_x, a.tiles_y);
+        const TileXY t = tile_of(tile, a);
         const WinOrg o = window_origin(a, t);
 #pragma unroll
         for (int j = 0; j < I; ++j) {
@@ -864,7 +881,7 @@ struct ProdFlow { float u[kProdPx], v[kProdPx]; WinOrg org; TileXY t; };      //
 // the flow at this lane's halo pixels and the window origin of `tile`: issued at the START of the last step of the tile before,
 // used at its end (a dependent global load behind a barrier would cost the producers ~1 us per tile)
 __device__ __forceinline__ void prod_fetch_flow(ProdFlow &pf, const PipeArgs &a, int tile, int pw, int lane) {
-    pf.t = tile_of(tile, a.nblk, a.tiles_x, a.tiles_y);
+    pf.t = tile_of(tile, a);
     const int plane = a.H * a.W;
     const float *fu = a.flo + (int64_t)pf.t.b * a.bsf;
 #pragma unroll
@@ -891,8 +908,9 @@ __device__ __forceinline__ void prod_setup(ProdPx (&px)[kProdPx], const PipeArgs
         px[k].wa = inimg ? pt.wa : 0.f; px[k].wb_ = inimg ? pt.wb : 0.f; px[k].wc = inimg ? pt.wc : 0.f; px[k].wd = inimg ? pt.wd : 0.f;
         px[k].otop = pt.otop * 4;
         px[k].obot = pt.obot * 4;
-        const int rt = pt.rtop, xb = pt.xb, rb = pt.rbot;           // (rows and column straight from the taps: four integer divisions per pixel, ~35
-                                                                        //  instructions each, sat here and in make_pair_taps -- 100-103 -> 96.8 us without them)
+        // rows and column straight from the taps: no runtime integer division (~35 instructions each on gfx950; four per pixel here and
+        // in make_pair_taps cost 1.7 us of the kernel's 100 -- this is the step the whole workgroup waits for)
+        const int rt = pt.rtop, xb = pt.xb, rb = pt.rbot;
         const int wr = rt - pf.org.wy0, wr2 = rb - pf.org.wy0, wc = xb - pf.org.wx0;
         const bool inside = ((wr >= 0) && (wr2 < kWR) && (wr2 >= wr) && (wc >= 0) && (wc + 1 < kWC) && !(PWC_PIPE_EXP & 2048)) || (PWC_PIPE_EXP & 8192);
         px[k].wt = inside ? ((PWC_PIPE_EXP & 8192) ? min(max(wr, 0), kWR - 2) * kWC + min(max(wc, 0), kWC - 2) : wr * kWC + wc) : -1;
@@ -1138,13 +1156,22 @@ bool warp_corr81_pipe_fits(int B, int C, int H, int W) {
     return mode > 0 && (nch == 8 || (nch == 16 && mode >= 2)) && W >= 2 && corr81_pipe_fits(B, C, H, W);
 }
 
+// reciprocals for tile_of(); false when the exactness bound does not hold (then the caller's other kernels run)
+static bool fill_magic(PipeArgs &a) {
+    if (a.tiles_x < 1 || a.tiles_y < 1 || (int64_t)a.nblk * a.tiles_x >= (1ll << 32) || (int64_t)a.nblk * a.tiles_y >= (1ll << 32)) return false;
+    a.magic_tx = a.tiles_x == 1 ? 0u : (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x);       // (1: not used)
+    a.magic_ty = a.tiles_y == 1 ? 0u : (unsigned)(((1ull << 32) + a.tiles_y - 1) / a.tiles_y);
+    return true;
+}
+
 int launch_corr81_pipe(const float *in1, const float *in2, float *out, int B, int C, int H, int W,
                        int64_t bs1, int64_t bs2, int64_t bso, float scale, float slope, int do_leaky, hipStream_t st) {
     const int tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kTH - 1) / kTH;
     const int nblk = B * tiles_x * tiles_y;
     const int nch = (C + kCK - 1) / kCK;
     const int grid = nblk < 256 ? nblk : 256;       // one workgroup per CU (its LDS does not admit two)
-    PipeArgs a{in1, in2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0, nullptr, 0, 0.f, 0.f, 0};
+    PipeArgs a{in1, in2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0, nullptr, 0, 0.f, 0.f, 0, 0u, 0u};
+    if (!fill_magic(a)) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_corr_fwd: too many tiles for the pipelined kernels");
     if (nch == 8 && option(OPT_CORR_ROLL)) {
         // runs of seg_len tiles down a column: as long as possible while the runs still cover the chip about once
         int seg_len = nblk / 256;
@@ -1178,8 +1205,9 @@ int launch_warp_corr81_pipe(const float *in1, const float *x2, const float *flo,
     const int nblk = B * tiles_x * tiles_y;
     const int nch = (C + kCK - 1) / kCK;
     const int grid = nblk < 256 ? nblk : 256;
-    const PipeArgs a{in1, x2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0,
-                     flo, bsf, flow_scale, thr, align_corners};
+    PipeArgs a{in1, x2, out, C, H, W, tiles_x, tiles_y, nblk, bs1, bs2, bso, scale, slope, do_leaky, 0, 0, 0,
+               flo, bsf, flow_scale, thr, align_corners, 0u, 0u};
+    if (!fill_magic(a)) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_warp_corr81_fwd: too many tiles for the window kernel");
     if (nch == 8) {
         int rc = ensure_lds_attr(g_lds_warp8, reinterpret_cast<const void *>(warp_corr81_pipe_kernel<8>), kLdsWarp, "warp_corr81_pipe_kernel<8>");
         if (rc != PWC_OK) return rc;
