@@ -68,6 +68,8 @@ const char *pwc_last_error(void);
 /* Run-time switches of the kernel selection (process-wide; tests and A/B benchmarks flip them instead of relying on an
  * environment variable being read before first use).  Each option's default comes from the environment variable in brackets:
  *   "conv_wino4" [PWC_CONV_WINO4] 1, "w4_tailsplit" [PWC_W4_TAILSPLIT] 1, "w4_smallsplit" [PWC_W4_SMALLSPLIT] 1,
+ *   "w4_small_min_wgs" [PWC_W4_SMALL_MIN_WGS] 160 (workgroups -- tiles x cout groups x Cin slices -- a launch smaller than the chip must reach for
+ *   pwc_conv3x3_wino4_preferred to take it; 96 / 64 measured within +-0.6 % / slower on the whole forward),
  *   "corr_pipe" [PWC_CORR_PIPE] 0 (plain correlation on the round-4 pipelined kernels), "corr_roll" [PWC_CORR_ROLL] 1 (their rolling form),
  *   "corr_pipe_min_tiles" [PWC_CORR_PIPE_MIN_TILES] 1024 (8x32 tiles a launch needs for the round-4 kernels),
  *   "corr_small_tiles" [PWC_CORR_SMALL_TILES] 48 (launches of at most this many 8x32 tiles use the small-map correlation kernel, and

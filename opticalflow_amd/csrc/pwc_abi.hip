@@ -36,6 +36,7 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"conv_wino4", "PWC_CONV_WINO4", 1},                  // F(4x4) route allowed (pwc_conv3x3_wino4_preferred)
     {"w4_tailsplit", "PWC_W4_TAILSPLIT", 1},              // partial last round of an F(4x4) launch cut along Cin
     {"w4_smallsplit", "PWC_W4_SMALLSPLIT", 1},            // launches that do not fill the chip cut along Cin (small batches)
+    {"w4_small_min_wgs", "PWC_W4_SMALL_MIN_WGS", 160},     // workgroups (tiles x cout groups x Cin slices) a small F(4x4) launch must reach to be preferred
     {"corr_pipe", "PWC_CORR_PIPE", 0},                    // PLAIN correlation on the round-4 pipelined / rolling kernels (pwc_corr_pipe.hip): parity with
                                                           // the round-2 kernel at level 2, slower at level 3 -- opt-in (profiles/r04_corr_notes.md)
     {"corr_pipe_min_tiles", "PWC_CORR_PIPE_MIN_TILES", 1024},

@@ -730,7 +730,7 @@ extern "C" int pwc_conv3x3_wino4_preferred(int B, int Cin, int H, int W, int Cou
         if (nwg >= 200) return true;
         if (!pwc::option(pwc::OPT_W4_SMALLSPLIT)) return false;
         const int k = wino4_small_ksplit(nwg, nchunks, device_cus());
-        return nwg * k >= 160 && nchunks / k >= 6;
+        return nwg * k >= pwc::option(pwc::OPT_W4_SMALL_MIN_WGS) && nchunks / k >= 6;
     };
     if (n32 >= 2) {
         const int th = 2 * gh;
