@@ -64,6 +64,9 @@ extern "C" {
                                  MFMA passes otherwise (the strict half-precision mode's level-2 / context layers)        */
 
 int pwc_abi_version(void);
+/* 0 for the product.  Bits: a kernel source was built with a timing-experiment switch (1 F(4x4) conv, 2 correlation, 4 pipelined
+ * correlation, 8 streaming heads): such a library skips work and its results are invalid; never ship or benchmark one. */
+int pwc_experiment_mask(void);
 const char *pwc_last_error(void);
 /* Run-time switches of the kernel selection (process-wide; tests and A/B benchmarks flip them instead of relying on an
  * environment variable being read before first use).  Each option's default comes from the environment variable in brackets:

@@ -25,6 +25,7 @@ FLAG_CONV_SPLIT2 = 32
 # name -> (restype, argtypes); mirrors include/pwc_hip.h one to one
 SIGNATURES = {
     "pwc_abi_version": (c_int, []),
+    "pwc_experiment_mask": (c_int, []),
     "pwc_last_error": (c_char_p, []),
     "pwc_last_conv_kernel": (c_char_p, []),
     "pwc_set_option": (c_int, [c_char_p, c_int]),
@@ -121,6 +122,11 @@ def load() -> ctypes.CDLL:
     got = lib.pwc_abi_version()
     if got != ABI_VERSION:
         raise PwcHipError("libpwc_hip.so ABI %d, binding expects %d -- rebuild" % (got, ABI_VERSION))
+    exp = lib.pwc_experiment_mask()
+    if exp and not os.environ.get("PWC_HIP_LIB"):
+        # a timing-experiment build (-DPWC_*_EXP: work skipped, results invalid) must never pass as the product
+        raise PwcHipError("%s was built with timing-experiment switches (mask %d): results would be invalid -- rebuild it "
+                          "(make -C opticalflow_amd/csrc) or select an experiment library explicitly with PWC_HIP_LIB" % (LIB_PATH, exp))
     _lib = lib
     return lib
 

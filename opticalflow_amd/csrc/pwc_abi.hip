@@ -87,4 +87,12 @@ extern "C" const char *pwc_last_conv_kernel(void) {
 
 extern "C" int pwc_abi_version(void) { return PWC_ABI_VERSION; }
 
+// Non-zero when a kernel source was compiled with a timing-experiment switch (-DPWC_*_EXP=mask: parts of the work are skipped, the
+// results are INVALID).  Such builds are made next to the product by tools/variant_build.sh and selected with PWC_HIP_LIB; the Python
+// binding refuses one as the default library.
+namespace pwc { int exp_mask_wino4(); int exp_mask_corr(); int exp_mask_corr_pipe(); int exp_mask_stream3x3(); }
+extern "C" int pwc_experiment_mask(void) {
+    return (pwc::exp_mask_wino4() ? 1 : 0) | (pwc::exp_mask_corr() ? 2 : 0) | (pwc::exp_mask_corr_pipe() ? 4 : 0) | (pwc::exp_mask_stream3x3() ? 8 : 0);
+}
+
 extern "C" const char *pwc_last_error(void) { return pwc::g_err; }

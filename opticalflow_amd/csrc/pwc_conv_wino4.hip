@@ -819,3 +819,6 @@ extern "C" int pwc_lattice_unsplit_f32(const void *x, void *y, int B, int C, int
                        static_cast<const float *>(x), static_cast<float *>(y), C, h, w, levels, y_bstride, total);
     return pwc::check_launch("lattice_unsplit_kernel");
 }
+
+// timing-experiment mask this translation unit was built with (0 in the product; pwc_experiment_mask)
+namespace pwc { int exp_mask_wino4() { return PWC_W4_EXP; } }

@@ -944,3 +944,6 @@ extern "C" int pwc_corr_bwd(const void *in1, const void *in2, const void *grad_o
     }
     return pwc::check_launch("corr_bwd_generic_kernel");
 }
+
+// timing-experiment mask this translation unit was built with (0 in the product; pwc_experiment_mask)
+namespace pwc { int exp_mask_corr() { return PWC_CORR_EXP; } }

@@ -1221,3 +1221,6 @@ int launch_warp_corr81_pipe(const float *in1, const float *x2, const float *flo,
 }
 
 }  // namespace pwc
+
+// timing-experiment mask this translation unit was built with (0 in the product; pwc_experiment_mask)
+namespace pwc { int exp_mask_corr_pipe() { return PWC_PIPE_EXP; } }

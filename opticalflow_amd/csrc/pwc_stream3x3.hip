@@ -429,3 +429,6 @@ int stream3x3_head_upfeat(const float *x, int B, int Cin, int H, int W, int64_t 
 }
 
 }  // namespace pwc_conv
+
+// timing-experiment mask this translation unit was built with (0 in the product; pwc_experiment_mask)
+namespace pwc { int exp_mask_stream3x3() { return PWC_STREAM_EXP; } }

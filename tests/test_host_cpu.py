@@ -30,6 +30,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), "library does not export %s" % n
     assert _lib.load().pwc_abi_version() == _lib.ABI_VERSION
+    assert _lib.load().pwc_experiment_mask() == 0          # the product is never a timing-experiment build (-DPWC_*_EXP: results invalid)
 
 
 def test_abi_argument_errors_without_gpu():
