@@ -262,7 +262,16 @@ warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo,
         v = acc1 * flow_scale;
         const _Float16 *cs = e.c1 + (int64_t)b * e.bs_c1 + (int64_t)pix * 8;
         _Float16 *cd = e.c1_dst + (int64_t)b * e.bs_c1dst + (int64_t)pix * 8;
-        for (int g = 0; g < Cg; ++g, cs += plane * 8, cd += plane * 8)
+        // four groups' loads in flight before the first store (the loop as written made one round trip per group)
+        int g = 0;
+        for (; g + 4 <= Cg; g += 4, cs += 4 * plane * 8, cd += 4 * plane * 8) {
+            h8 r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const h8 *>(cs + (int64_t)q * plane * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<h8 *>(cd + (int64_t)q * plane * 8) = r[q];
+        }
+        for (; g < Cg; ++g, cs += plane * 8, cd += plane * 8)
             *reinterpret_cast<h8 *>(cd) = *reinterpret_cast<const h8 *>(cs);
     } else {
         const _Float16 *f = flo + (int64_t)b * bsf + (int64_t)pix * 8 + flo_channel;
@@ -272,7 +281,14 @@ warp_c8_kernel(const _Float16 *__restrict__ x, const _Float16 *__restrict__ flo,
     const Taps8 t = make_taps8(u, v, xx, yy, H, W, align_corners, thr);
     const _Float16 *src = x + (int64_t)b * bsx;
     _Float16 *dst = out + (int64_t)b * bso + (int64_t)pix * 8;
-    for (int g = 0; g < Cg; ++g, src += plane * 8, dst += plane * 8) *reinterpret_cast<h8 *>(dst) = blend_taps8(src, t);
+    // two groups' eight taps in flight (four: 64 more registers, one workgroup less per CU)
+    int g = 0;
+    for (; g + 2 <= Cg; g += 2, src += 2 * plane * 8, dst += 2 * plane * 8) {
+        const h8 r0 = blend_taps8(src, t), r1 = blend_taps8(src + plane * 8, t);
+        *reinterpret_cast<h8 *>(dst) = r0;
+        *reinterpret_cast<h8 *>(dst + plane * 8) = r1;
+    }
+    for (; g < Cg; ++g, src += plane * 8, dst += plane * 8) *reinterpret_cast<h8 *>(dst) = blend_taps8(src, t);
 }
 
 // ---- level entry + warp + correlation in ONE kernel (VERDICT r3 next #1c) ----------------------------------------------------------
