@@ -104,7 +104,7 @@ class AsyncFlowGather:
     gather k (26 MB into rank 0 at N = 8, an estimated 0.2-0.3 ms of a 10.7 ms step).  Here the flows of step k are copied into one of
     two staging buffers on a SIDE stream (which waits for an event recorded behind forward k), the collective is issued on that
     stream (RCCL orders itself after the stream that is current when it is called), and an event marks its end; the compute stream
-    never waits for any of it.  ``submit`` returns at once; ``result(k)`` gives step k's gathered tensor on ``dst`` (None elsewhere)
+    waits for the staging copy only (microseconds), never for the collective.  ``submit`` returns at once; ``result(k)`` gives step k's gathered tensor on ``dst`` (None elsewhere)
     after making the CALLER's stream wait for its event -- valid until the submit two steps later reuses the buffers.  With a CPU
     / gloo group there are no streams and the call degenerates to the synchronous gather: same results, which is what the
     world-size-2 test pins; the overlap itself is checked on the GPU with event timestamps (tests/test_gpu_rccl.py)."""
@@ -121,6 +121,7 @@ class AsyncFlowGather:
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.ready = [torch.cuda.Event() for _ in range(2)] if self.cuda else None          # recorded behind the forward
         self.done = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.cuda else None   # recorded behind the gather
+        self.copied = [torch.cuda.Event() for _ in range(2)] if self.cuda else None         # recorded behind the copy into staging
         self.out = [None, None]
         self.k = 0
 
@@ -135,10 +136,15 @@ class AsyncFlowGather:
         self.ready[i].record(cur)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ready[i])
-            self.stage[i].copy_(local, non_blocking=True)        # the caller may overwrite / free `local` once its own stream moves on
+            self.stage[i].copy_(local, non_blocking=True)
+            self.copied[i].record(self.side)
             local.record_stream(self.side)
             self.out[i] = self.g[i](self.stage[i])
             self.done[i].record(self.side)
+        # The caller's stream waits for the COPY (a few microseconds of device-to-device traffic that start the moment the forward
+        # ends), not for the collective: `local` may be a buffer the next forward writes again (PWCDCNet(borrow_output=True) hands out
+        # the plan's own flow buffer), and without this the copy would merely be very likely to win that race.
+        cur.wait_event(self.copied[i])
         return k
 
     def result(self, k: int) -> Optional[torch.Tensor]:
