@@ -55,17 +55,22 @@ __device__ __forceinline__ void *uniform_ptr(const void *p) {
     return reinterpret_cast<void *>(((uint64_t)hi << 32) | lo);
 }
 
-template <int MT, int NT, int S, int D, int TWO, int CKO = 0>
+// FOLD (maps of at most 16 columns: pyramid / decoder level 6 at 448x1024): the 32 MFMA columns are 16 pixel columns x two groups of
+// four rows -- an 8 x 16 pixel tile -- instead of 4 x 32: a 7x16 map is ONE tile at 7/8 use instead of two tiles at 7/16.  Only the lane
+// -> pixel mapping changes (column = lane % 16, row += 4 * (lane / 16 % 2)); stride 1, dilation 1, MT = NT = 1.
+template <int MT, int NT, int S, int D, int TWO, int CKO = 0, int FOLD = 0>
 struct Geom {
+    static_assert(!FOLD || (MT == 1 && NT == 1 && S == 1 && D == 1), "folded tile: 1x1 tiles of the plain stride-1 kernel only");
     static constexpr int kCK = CKO ? CKO : (TWO ? 4 : 8);           // input channels per chunk
     static constexpr int kWPS = TWO ? 2 : 1;                        // waves per SIMD the register budget must allow
-    static constexpr int kTileH = 4 * NT;
+    static constexpr int kTW = FOLD ? 16 : 32;                      // pixel columns of a tile
+    static constexpr int kTileH = FOLD ? 8 : 4 * NT;
     static constexpr bool kRowSep = (D >= 16);                      // stage the three ky row-sets separately
     // A staged row starts kPadL >= D columns left of the tile, at a multiple of four input columns, and is a whole number of 16-byte
     // pieces long: with W % 4 == 0 and 16-byte aligned tensors the tile then arrives as 16-byte LDS-DMA pieces (round 3: a third of the
     // instructions of the dword form -- each costs the issuing wave 60-180 cycles -- which remains for other widths / alignments).
     static constexpr int kPadL = (D + 3) / 4 * 4;
-    static constexpr int kInW = (kPadL + (kTileW - 1) * S + 1 + D + 3) / 4 * 4;    // row pitch (floats)
+    static constexpr int kInW = (kPadL + (kTW - 1) * S + 1 + D + 3) / 4 * 4;       // row pitch (floats)
     static constexpr int kCol0 = kPadL - D;                                        // staged index of the tile's first window column
     static constexpr int kInH = kRowSep ? 3 * kTileH : (kTileH - 1) * S + 2 * D + 1;
     static constexpr int kCH = kInH * kInW;                          // floats per staged channel (flat)
@@ -122,13 +127,13 @@ __device__ __forceinline__ void issue_chunk(const float *xb, const float *wg, in
 // y = workspace [z][b][Cout][Ho][Wo] (bsy = Cout*Ho*Wo, zstride = B*bsy); bias / activation / residual are applied by
 // splitk_reduce_kernel, which adds the partials in fixed z order (deterministic).  Used when a layer has too
 // few output tiles to occupy 256 CUs and a long Cin (levels 6-4, batch-1 inference).
-template <int MT, int NT, int S, int D, int TWO, int SPLIT>
+template <int MT, int NT, int S, int D, int TWO, int SPLIT, int FOLD = 0>
 __global__ void __launch_bounds__(kThreads, (TWO ? 2 : 1))
 conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                     const float *__restrict__ residual, float *__restrict__ y,
                     int Cin, int H, int W, int Cout, int CoutP, int Ho, int Wo, int tiles_x, int tiles_y,
                     int64_t bsx, int64_t bsy, int64_t bsr, float slope, int do_leaky, int cps, int64_t zstride, int p16i) {
-    using G = Geom<MT, NT, S, D, TWO>;
+    using G = Geom<MT, NT, S, D, TWO, 0, FOLD>;
     const bool p16 = __builtin_amdgcn_readfirstlane(p16i) != 0;
     constexpr int CK = G::kCK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -136,7 +141,8 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int col = lane & 31;
+    const int col = FOLD ? (lane & 15) : (lane & 31);               // pixel column inside the tile
+    const int frow = FOLD ? ((lane >> 4) & 1) * 4 : 0;              // folded tile: MFMA columns 16..31 are rows 4..7
     const int kh = lane >> 5;
 
     int bid = blockIdx.x;
@@ -149,7 +155,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int g = blockIdx.y;
-    const int ox0 = tx * kTileW;
+    const int ox0 = tx * G::kTW;
     const int oy0 = ty * G::kTileH;
     const int plane = H * W;
 
@@ -218,8 +224,8 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
             issue_chunk<G>(xb, wg, chunk + 1, Cin, plane, wchunk, wbytes, wave, smem + ((chunk + 1) & 1) * G::kBufFloats,
                            in_off, w_off, p16);
 
-        const float *rd_in = cur + kh * G::kCH + (wave * NT) * S * G::kInW + col * S + G::kCol0;
-        const float *rd_w = cur + G::kInRegion + kh * 9 * G::kCoutT + col;
+        const float *rd_in = cur + kh * G::kCH + (wave * NT + frow) * S * G::kInW + col * S + G::kCol0;
+        const float *rd_w = cur + G::kInRegion + kh * 9 * G::kCoutT + (lane & 31);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -245,7 +251,7 @@ conv3x3_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wp, c
     const int64_t oplane = (int64_t)Ho * Wo;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int oy = oy0 + wave * NT + nt;
+        const int oy = oy0 + wave * NT + nt + frow;
         if (oy >= Ho || ox >= Wo) continue;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -414,9 +420,15 @@ struct ConvArgs {
 // Split-K plan shared by pwc_conv2d_fwd and pwc_conv2d_workspace_bytes: ksplit (1 = do not split) and the
 // 8-channel chunks per split, for a stride-1 dilation-1 layer run with the 4x32-pixel x 32-cout tile.
 struct SplitPlan { int ksplit, cps; };
+// maps of at most 16 columns and more than one 4-row strip take the folded 8 x 16 tile (Geom FOLD); stride 1, dilation 1 only
+inline bool fold_tile(int Ho, int Wo) {
+    static const bool on = [] { const char *e = getenv("PWC_CONV_FOLD"); return !(e && e[0] == '0'); }();
+    return on && Wo <= 16 && Ho > 4;
+}
 inline SplitPlan plan_split(int B, int Cin, int Ho, int Wo, int CoutP) {
     static const int knob = [] { const char *e = getenv("PWC_CONV_SPLIT"); return (e && *e) ? atoi(e) : -1; }();
-    const int64_t blocks = (int64_t)B * ((Wo + kTileW - 1) / kTileW) * ((Ho + 3) / 4) * (CoutP / 32);
+    const int64_t blocks = fold_tile(Ho, Wo) ? (int64_t)B * ((Ho + 7) / 8) * (CoutP / 32)
+                                             : (int64_t)B * ((Wo + kTileW - 1) / kTileW) * ((Ho + 3) / 4) * (CoutP / 32);
     const int nchunks = (Cin + 7) / 8;
     // measured (tools/sweep_split.sh): a short K only pays when the grid is nearly empty
     if (knob == 0 || blocks > 256 || nchunks < (blocks <= 64 ? 8 : 16)) return {1, nchunks};
@@ -432,38 +444,38 @@ inline SplitPlan plan_split(int B, int Cin, int Ho, int Wo, int CoutP) {
 
 namespace {
 
-template <int MT, int NT, int S, int D, int TWO>
+template <int MT, int NT, int S, int D, int TWO, int FOLD = 0>
 int launch(const ConvArgs &a) {
-    using G = Geom<MT, NT, S, D, TWO>;
+    using G = Geom<MT, NT, S, D, TWO, 0, FOLD>;
     if constexpr (!G::kValid) {
         PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: internal: tile %dx%d two=%d does not exist", MT, NT, TWO);
     } else {
-        const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+        const int tiles_x = (a.Wo + G::kTW - 1) / G::kTW;
         const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
         const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
         const int groups = (a.CoutP / 32 + MT - 1) / MT;
         if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_conv2d_fwd: grid too large");
-        auto kern = conv3x3_mfma_kernel<MT, NT, S, D, TWO, 0>;
+        auto kern = conv3x3_mfma_kernel<MT, NT, S, D, TWO, 0, FOLD>;
         static pwc::LdsAttrOnce attr;   // one per instantiation, tracked per device
         if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmemBytes, "pwc_conv2d_fwd"))
             return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)groups), dim3(kThreads), G::kSmemBytes, a.stream,
                            a.x, a.wp, a.bias, a.residual, a.y, a.Cin, a.H, a.W, a.Cout, a.CoutP, a.Ho, a.Wo,
                            tiles_x, tiles_y, a.bsx, a.bsy, a.bsr, a.slope, a.do_leaky, 0, (int64_t)0, a.p16());
-        pwc::note_kernel("conv3x3_mfma_kernel", MT, NT, S, D, TWO, 0);
+        pwc::note_kernel("conv3x3_mfma_kernel", MT, NT, S, D, TWO, FOLD ? 16 : 0);        // (last field: 16 = folded 8 x 16 tile)
         return pwc::check_launch("conv3x3_mfma_kernel");
     }
 }
 
 // split-K launch of the 4x32 x 32-cout tile (CK = 8): raw partials into a.partial
-template <int S, int D>
+template <int S, int D, int FOLD = 0>
 int launch_split(const ConvArgs &a) {
-    using G = Geom<1, 1, S, D, 0>;
-    const int tiles_x = (a.Wo + kTileW - 1) / kTileW;
+    using G = Geom<1, 1, S, D, 0, 0, FOLD>;
+    const int tiles_x = (a.Wo + G::kTW - 1) / G::kTW;
     const int tiles_y = (a.Ho + G::kTileH - 1) / G::kTileH;
     const int64_t nblk = (int64_t)a.B * tiles_x * tiles_y;
     const int groups = a.CoutP / 32;
-    auto kern = conv3x3_mfma_kernel<1, 1, S, D, 0, 1>;
+    auto kern = conv3x3_mfma_kernel<1, 1, S, D, 0, 1, FOLD>;
     static pwc::LdsAttrOnce attr;
     if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), G::kSmemBytes, "pwc_conv2d_fwd"))
         return rc;

@@ -1493,3 +1493,38 @@ def test_head10_conv_and_upsample_entry_vs_fp64(gpu_device, case):
     assert (arena[:, 5:7].cpu().double() - up_feat).abs().max().item() <= tol
     with pytest.raises(ValueError):
         ops.upsample_entry(head[:, :9], wd.to(dev), bd.to(dev), arena[:, 3:7])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(32, 196, 196, 7, 16, False), (2, 128, 196, 7, 16, True), (3, 37, 33, 9, 11, False), (1, 529, 128, 12, 8, True),
+                                  (2, 64, 96, 5, 16, False), (4, 213, 64, 17, 13, True)])
+def test_conv3x3_folded_tile_small_maps(gpu_device, case):
+    """Maps of at most 16 columns (pyramid / decoder level 6 at 448x1024: 7x16) run the direct MFMA kernel on a FOLDED tile: the 32
+    MFMA columns are 16 pixel columns x two groups of four rows (8 x 16 pixels), so a 7x16 map is one tile at 7/8 use instead of two
+    4x32 tiles at 7/16 (conv6a / conv6b 62 -> ~35 us at batch 16).  Unsplit and split-K forms against torch's fp64 conv2d: odd
+    widths and heights, ragged channel chunks and cout groups, bias, LeakyReLU, residual, arena-strided output."""
+    from opticalflow_amd import ops, _lib
+    B, cin, cout, H, W, split = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g)
+    dev = gpu_device
+    ws = None
+    if split:
+        need = ops.conv3x3_workspace_bytes(B, cin, H, W, cout)
+        assert need > 0
+        ws = torch.empty(need // 4, device=dev)
+    arena = torch.full((B, cout + 4, H, W), 7.0, device=dev)
+    ops.conv3x3(x.to(dev), ops.pack_conv3x3(w.to(dev)), b.to(dev), cout, leaky_slope=0.1, residual=res.to(dev), out=arena[:, 2:2 + cout], workspace=ws)
+    kern = _lib.load().pwc_last_conv_kernel().decode()
+    if not split:
+        assert kern.rstrip(">").split(",")[-1].strip() == "16", kern                   # the folded 8 x 16 tile ran
+    assert (arena[:, :2] == 7).all() and (arena[:, 2 + cout:] == 7).all()
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1) + res.double()
+    err = (arena[:, 2:2 + cout].cpu().double() - ref).abs().max().item()
+    assert err <= 3e-6 * (cin * 9) ** 0.5, (case, err)
+    again = torch.empty(B, cout, H, W, device=dev)
+    ops.conv3x3(x.to(dev), ops.pack_conv3x3(w.to(dev)), b.to(dev), cout, leaky_slope=0.1, residual=res.to(dev), out=again, workspace=ws)
+    assert torch.equal(again, arena[:, 2:2 + cout])
