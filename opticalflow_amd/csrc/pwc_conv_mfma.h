@@ -57,10 +57,10 @@ __device__ __forceinline__ void *uniform_ptr(const void *p) {
 
 // FOLD (maps of at most 16 columns: pyramid / decoder level 6 at 448x1024): the 32 MFMA columns are 16 pixel columns x two groups of
 // four rows -- an 8 x 16 pixel tile -- instead of 4 x 32: a 7x16 map is ONE tile at 7/8 use instead of two tiles at 7/16.  Only the lane
-// -> pixel mapping changes (column = lane % 16, row += 4 * (lane / 16 % 2)); stride 1, dilation 1, MT = NT = 1.
+// -> pixel mapping changes (column = lane % 16, row += 4 * (lane / 16 % 2)); dilation 1, MT = NT = 1 (stride 1 and 2).
 template <int MT, int NT, int S, int D, int TWO, int CKO = 0, int FOLD = 0>
 struct Geom {
-    static_assert(!FOLD || (MT == 1 && NT == 1 && S == 1 && D == 1), "folded tile: 1x1 tiles of the plain stride-1 kernel only");
+    static_assert(!FOLD || (MT == 1 && NT == 1 && D == 1), "folded tile: 1x1 tiles, dilation 1");
     static constexpr int kCK = CKO ? CKO : (TWO ? 4 : 8);           // input channels per chunk
     static constexpr int kWPS = TWO ? 2 : 1;                        // waves per SIMD the register budget must allow
     static constexpr int kTW = FOLD ? 16 : 32;                      // pixel columns of a tile

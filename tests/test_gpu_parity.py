@@ -1528,3 +1528,20 @@ def test_conv3x3_folded_tile_small_maps(gpu_device, case):
     again = torch.empty(B, cout, H, W, device=dev)
     ops.conv3x3(x.to(dev), ops.pack_conv3x3(w.to(dev)), b.to(dev), cout, leaky_slope=0.1, residual=res.to(dev), out=again, workspace=ws)
     assert torch.equal(again, arena[:, 2:2 + cout])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(32, 128, 196, 14, 32), (2, 37, 40, 9, 21), (1, 16, 32, 11, 30)])
+def test_conv3x3_stride2_folded_tile(gpu_device, case):
+    """Stride-2 layers whose OUTPUT has at most 16 columns (conv6aa: 14x32 -> 7x16) take the folded 8 x 16 tile too; vs fp64 conv2d."""
+    from opticalflow_amd import ops, _lib
+    B, cin, cout, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    got = ops.conv3x3(x.to(gpu_device), ops.pack_conv3x3(w.to(gpu_device)), b.to(gpu_device), cout, stride=2, leaky_slope=0.1)
+    assert _lib.load().pwc_last_conv_kernel().decode().rstrip(">").split(",")[-1].strip() == "16"
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1), 0.1)
+    assert got.shape == ref.shape
+    assert (got.cpu().double() - ref).abs().max().item() <= 3e-6 * (cin * 9) ** 0.5
