@@ -404,3 +404,22 @@ def test_strict_mode_default_filter_policy(monkeypatch):
         importlib.reload(engine_strict)
     monkeypatch.delenv("PWC_STRICT_PLAIN")
     importlib.reload(engine_strict)
+
+
+def test_deconv_as_conv3x3_is_the_transposed_convolution():
+    """ops.deconv_as_conv3x3: ConvTranspose2d(k4, s2, p1) (upfeatL / deconvL, models/PWCNet.py:35-36) restated as a 3x3 convolution with
+    four output phases per channel + pixel shuffle -- the form the small levels run on the matrix cores together with the flow head
+    (pwc_upsample_entry_f32 does the shuffle).  Pure host arithmetic, checked against torch's conv_transpose2d in fp64."""
+    import torch.nn.functional as F
+    from opticalflow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for cin, cout, h, w in ((5, 2, 7, 16), (3, 3, 4, 5), (8, 2, 1, 1)):
+        x = torch.randn(2, cin, h, w, generator=g, dtype=torch.float64)
+        wt = torch.randn(cin, cout, 4, 4, generator=g, dtype=torch.float64)
+        b = torch.randn(cout, generator=g, dtype=torch.float64)
+        ref = F.conv_transpose2d(x, wt, b, stride=2, padding=1)
+        k = ops.deconv_as_conv3x3(wt)                                     # [cout*4, cin, 3, 3], channel co*4 + py*2 + px
+        assert tuple(k.shape) == (cout * 4, cin, 3, 3)
+        ph = F.conv2d(x, k, b.repeat_interleave(4), padding=1)            # [B, cout*4, h, w]
+        got = F.pixel_shuffle(ph, 2)                                       # channel co*4 + py*2 + px -> (co, 2y+py, 2x+px)
+        assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-12
