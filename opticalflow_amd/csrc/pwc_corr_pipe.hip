@@ -1016,6 +1016,9 @@ __device__ __forceinline__ void prod_steps(ProdState &ps, const PipeArgs &a, flo
 
 template <int NCH>
 __device__ __forceinline__ void producer_wave(const PipeArgs &a, float *s2ring, const float *win, int pw, int lane, int my_tiles) {
+    // the producers' chain is the kernel's critical path and they share their SIMDs with fma waves: issue priority above those
+    // (loaders: 3).  Interleaved same-box pairs: 100.8 / 98.8 us without, 96.2-96.7 with priority 1 or 2, 99.1 with 3.
+    __builtin_amdgcn_s_setprio(2);
     const int stride = gridDim.x, nsteps = my_tiles * NCH;
     ProdState ps;
     {
