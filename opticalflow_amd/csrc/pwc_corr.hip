@@ -377,6 +377,11 @@ corr81_dma_kernel(const float *__restrict__ in1, const float *__restrict__ in2, 
         if (wave > kLoaderWave) {
             // ================= warp producers: chunk s+2 is written while the fma waves consume chunk s ===========
             const int pw = wave - (kLoaderWave + 1);
+#ifndef PWC_CORR_PROD_PRIO
+#define PWC_CORR_PROD_PRIO 2
+#endif
+            // issue priority above the fma waves these waves share their SIMDs with (the loader runs at 3): the producers set the pace
+            if (PWC_CORR_PROD_PRIO) __builtin_amdgcn_s_setprio(PWC_CORR_PROD_PRIO);
             // (A variant that software-pipelined the two halo pixels of a lane as half-chunks -- one half's gathers in flight
             // while the other is blended -- measured SLOWER, 131 vs 119 us at level 2: the producers are bound by instruction
             // issue next to nine fma waves, not by gather latency; they have two ring steps of slack per chunk anyway.)
