@@ -1545,3 +1545,27 @@ def test_conv3x3_stride2_folded_tile(gpu_device, case):
     ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1), 0.1)
     assert got.shape == ref.shape
     assert (got.cpu().double() - ref).abs().max().item() <= 3e-6 * (cin * 9) ** 0.5
+
+
+@pytest.mark.gpu
+def test_borrow_output_returns_the_plans_buffer(gpu_device):
+    """PWCDCNet(borrow_output=True): eval-mode forwards hand out the plan's own flow buffer (no copy) -- same values as the default, and
+    the NEXT forward of the same geometry overwrites it, which is the documented contract (bench.py's loop and the sharded gather
+    consume each flow before the next forward)."""
+    from opticalflow_amd import PWCDCNet
+    from opticalflow_amd.weights import synthetic_state_dict
+    x1 = torch.rand(1, 6, 128, 192, generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    x2 = torch.rand(1, 6, 128, 192, generator=torch.Generator().manual_seed(2)).to(gpu_device)
+    nets = {}
+    for borrow in (False, True):
+        net = PWCDCNet(borrow_output=borrow).to(gpu_device).eval()
+        net.load_state_dict(synthetic_state_dict(net.manifest(), seed=0, gain=0.85, bias_std=0.02))
+        nets[borrow] = net
+    with torch.no_grad():
+        a1, b1 = nets[False](x1), nets[True](x1)
+        assert torch.equal(a1, b1)
+        keep = b1.clone()
+        b2 = nets[True](x2)
+        a2 = nets[False](x2)
+    assert torch.equal(a2, b2) and b2.data_ptr() == b1.data_ptr()          # the same buffer, now holding the second flow
+    assert torch.equal(a1, keep) and not torch.equal(a1, a2)                # the default mode's first result is untouched
