@@ -81,7 +81,9 @@ const char *pwc_last_error(void);
  *   convolution followed by pwc_upsample_entry_f32; 0: pwc_conv2d_fwd + two pwc_deconv4x4s2_fwd),
  *   "f16_level_corr" [PWC_F16_LEVEL_CORR] 0 (1: the half-precision plans enter a level through pwc_level_corr81_c8_f16 instead of the two
  *   calls it fuses -- same bits, measured slower at batch 16),
- *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off).
+ *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off),
+ *   "c1_in_arena" [PWC_C1_IN_ARENA] 1 (fp32 plans: the level features of both images live at the arena's batch stride, so that the pyramid's
+ *   last convolution writes the first image's straight into their arena slot; 0: dense pyramid buffers and one copy per level).
  * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */
 int pwc_set_option(const char *name, int value);
 int pwc_get_option(const char *name, int *value);

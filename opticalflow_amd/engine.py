@@ -115,17 +115,30 @@ class PwcPlan:
         for l in range(1, 7):
             h, w = self.size[l]
             c = PYRAMID_CH[l]
-            self.pyr_a[l] = torch.empty((self._slots(B), c, h, w), **kw)
+            self.pyr_a[l] = torch.empty((self._slots(B), c, h, w), **kw)      # levels 2-5: replaced by a view of the arena below
             self.pyr_b[l] = torch.empty((self._slots(B), c, h, w), **kw)
-        for l in range(2, 7):
-            self.c1[l], self.c2[l] = self._pair_views(self.pyr_a[l], B)
         self.warped = {l: torch.empty((B, PYRAMID_CH[l], *self.size[l]), **kw) for l in range(2, 6)}
         self.arena = {}
         self.arena_base = {}                    # first channel after the dense-block outputs
+        # Levels 2-5: the first image's level features are part of the dense block's input (PWCNet.py:215), i.e. they
+        # have a slot in the level's arena.  Instead of copying them there, the level's pyramid buffer IS that slot: the arena is
+        # allocated for 2B items, items [0,B) are the decoder's arena, items [B,2B) only ever hold the second image's features in the
+        # same channel slot, and pyr_a[l] is the [2B, c, h, w] view of that slot at the arena's batch stride -- every kernel takes batch
+        # strides, so the pyramid's last convolution writes c1 where the decoder reads it (four copies, 47 us at batch 16, gone; the
+        # cost is address space: 2.1 GB instead of 1.0 GB at level 2 / batch 16).  Not for the video plan (its c1 / c2 overlap).
+        self.c1_in_arena = bool(conv_backend == "hip" and self._slots(B) == 2 * B and _lib.get_option("c1_in_arena"))
         for l in range(2, 7):
             od = level_in_channels(l, self.nd)
             self.arena_base[l] = DENSE_TOTAL if (l > 2 or trunk2) else 0
-            self.arena[l] = torch.empty((B, self.arena_base[l] + od, *self.size[l]), **kw)
+            if self.c1_in_arena and l < 6:
+                pair = torch.empty((2 * B, self.arena_base[l] + od, *self.size[l]), **kw)
+                self.arena[l] = pair[:B]
+                off = self.arena_base[l] + self.nd
+                self.pyr_a[l] = pair[:, off:off + PYRAMID_CH[l]]
+            else:
+                self.arena[l] = torch.empty((B, self.arena_base[l] + od, *self.size[l]), **kw)
+        for l in range(2, 7):
+            self.c1[l], self.c2[l] = self._pair_views(self.pyr_a[l], B)
         self.flow = {l: torch.empty((B, 2, *self.size[l]), **kw) for l in range(2 if trunk2 else 3, 7)}
         # Levels too small for the streaming head + upfeat kernel (W < 64: levels 6-5; all of 6-3 for a single pair): predict_flowL and
         # upfeatL run as ONE 3x3 convolution with 10 output channels on the matrix cores (ConvTranspose2d(k4,s2,p1) = a 3x3 convolution
@@ -397,7 +410,8 @@ class PwcPlan:
         off = base + nd
         # first image's level features go into the level's arena slot (they are part of the
         # dense block's input, PWCNet.py:215); c2 is only ever read by the warp
-        ar[:, off:off + c].copy_(self.c1[l])
+        if not self.c1_in_arena:
+            ar[:, off:off + c].copy_(self.c1[l])
         up_flow = ar[:, off + c:off + c + 2]
         # warp + correlation + LeakyReLU as one kernel (the warped features live in LDS only) where the geometry
         # allows it (md = 4, W % 4 == 0) and the map is more than a few tiles; otherwise the two operators
@@ -490,6 +504,9 @@ class PwcPlan:
         tot = 0
         for group in (self.pyr_a, self.pyr_b, self.warped, self.arena, self.flow):
             tot += sum(t.numel() * t.element_size() for t in group.values())
+        if self.c1_in_arena:                                    # pyr_a[2..5] are views of the arenas, which hold 2B items
+            for l in range(2, 6):
+                tot += (self.arena[l].numel() - self.pyr_a[l].numel()) * self.arena[l].element_size()
         tot += sum(t.numel() * t.element_size() for t in self.ctx + ([self.flow_out] if self.flow_out is not None else []))
         if getattr(self, "ctx_lattice", False):
             tot += self.ctx4_lat.numel() * self.ctx4_lat.element_size()

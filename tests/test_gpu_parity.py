@@ -1402,6 +1402,43 @@ def test_forward_context_lattice_layout_matches_plain_layout(gpu_device, monkeyp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [("dc", "fp32", 2, 128, 192), ("dc", "fp32", 1, 448, 1024), ("old", "fp32", 3, 64, 128),
+                                  ("dc", "fp16-strict", 2, 128, 256)])
+def test_forward_c1_in_arena_bit_identical_to_copy(gpu_device, case):
+    """Option c1_in_arena (the level features of both images live at the arena's batch stride, the pyramid's last convolution of
+    levels 2-5 writes the first image's straight into their arena slot) against the form with dense pyramid buffers and one copy per
+    level (PWCNet.py:215 concatenates c1 into the dense block's input): the same kernels on the same values at other addresses --
+    every flow of the training tuple bit-identical, eager and as a replayed graph, and the plan really is in the layout asked for."""
+    from opticalflow_amd import PWCDCNet, PWCDCNet_old, _lib
+    from opticalflow_amd.weights import synthetic_state_dict
+    variant, precision, B, H, W = case
+    x = torch.rand(B, 6, H, W, generator=torch.Generator().manual_seed(77 + B)).to(gpu_device)
+    saved = _lib.get_option("c1_in_arena")
+    out = {}
+    try:
+        for flag in (1, 0):
+            _lib.set_option("c1_in_arena", flag)
+            net = (PWCDCNet_old if variant == "old" else PWCDCNet)(precision=precision, use_graph=True)
+            net.load_state_dict(synthetic_state_dict(net.manifest(), seed=3, gain=0.85, bias_std=0.02))
+            net = net.to(gpu_device).eval()
+            with torch.no_grad():
+                first = net(x).clone()
+                again = net(x).clone()                             # a replay of the captured graph
+            plan = net._plan_for(x)
+            upper = getattr(plan, "upper", plan)
+            assert upper.c1_in_arena == bool(flag)
+            for l in range(2, 6):
+                assert (upper.c1[l].data_ptr() == upper.arena[l][:, upper.arena_base[l] + 81:].data_ptr()) == bool(flag)
+            assert torch.equal(first, again)
+            out[flag] = (first,) + tuple(t.clone() for t in upper.flow.values())
+    finally:
+        _lib.set_option("c1_in_arena", saved)
+    assert len(out[0]) == len(out[1])
+    for a, b in zip(out[1], out[0]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", [(8, 128, 64, 14, 32), (2, 40, 32, 30, 32), (3, 24, 96, 17, 28)])
 def test_conv3x3_winograd4_narrow_maps(gpu_device, case):
     """Maps of <= 32 columns (the 14x32 lattice images dc_conv4 runs on in the lattice-major context network) take the F(4x4) kernel's
