@@ -82,6 +82,10 @@ const char *pwc_last_error(void);
  *   "f16_level_corr" [PWC_F16_LEVEL_CORR] 0 (1: the half-precision plans enter a level through pwc_level_corr81_c8_f16 instead of the two
  *   calls it fuses -- same bits, measured slower at batch 16),
  *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off),
+ *   "stream_slice_wgs" [PWC_STREAM_SLICE_WGS] 512 (pwc_conv2d_fwd, 2-channel flow head on a map of 8..63 8-row x 128-column tiles --
+ *   predict_flow2 of one or two pairs, PWCNet.py:263: the streaming kernel runs on Cin slices, as many as bring the launch to this many
+ *   workgroups, partial sums in the caller's workspace (pwc_conv2d_workspace_bytes covers them), fixed-order reduction; 0: the split-K
+ *   MFMA kernel as before),
  *   "c1_in_arena" [PWC_C1_IN_ARENA] 1 (fp32 plans: the level features of both images live at the arena's batch stride, so that the pyramid's
  *   last convolution writes the first image's straight into their arena slot; 0: dense pyramid buffers and one copy per level).
  * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */

@@ -46,6 +46,8 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"f16_level_corr", "PWC_F16_LEVEL_CORR", 0},          // half-precision plans: level entry + warp + correlation as one kernel (read by the Python engine);
                                                           // bit-identical, but 97 vs 81 us at level 2 (2.5x halo gathers): opt-in
     {"warpcorr_window", "PWC_WARPCORR_WINDOW", 1},        // fused warp+correlation on the LDS-window kernel: 1 = C <= 32 (level 2), 2 = also C <= 64, 0 = round-2 kernel
+    {"stream_slice_wgs", "PWC_STREAM_SLICE_WGS", 512},    // streaming flow head (+ upfeat): launches whose 4-row tiles are under 3/4 of this many workgroups are cut along Cin
+                                                          // into slices (fixed-order reduction, needs the caller's workspace); 0 = off
     {"c1_in_arena", "PWC_C1_IN_ARENA", 1},                // fp32 plans: the pyramid's last convolution of levels 2-5 writes the first image's features straight into
                                                           // their slot of the decoder arena (batch-strided output) instead of a copy per level (read by the Python engine)
 };

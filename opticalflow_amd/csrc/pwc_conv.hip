@@ -4,6 +4,8 @@
 //   * the VALU kernel for the 2-channel flow heads (pwc_conv_head.hip).
 // Replaces nn.Conv2d(3x3)+LeakyReLU(0.1) (reference models/PWCNet.py:26-33) for every layer
 // PWCDCNet.forward runs (PWCNet.py:184-268).  The transposed convolutions live in pwc_deconv.hip.
+#include <algorithm>
+
 #include "pwc_conv_mfma.h"
 
 namespace pwc_conv {
@@ -19,9 +21,11 @@ int run_head(const float *x, const float *w_raw, const float *bias, const float 
 int image_conv_s2(const float *x, const float *wp, const float *bias, float *y, int B, int Cin, int H, int W, int Cout, int CoutP,
                   int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st);      // pwc_conv_image.hip
 bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx);
+bool stream3x3_head_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes);
+int64_t stream3x3_head_workspace_bytes(int B, int Cin, int H, int W);
 int stream3x3_head(const float *x, const float *w, const float *bias, const float *residual, float *y,
                    int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, int64_t bsr,
-                   float slope, int do_leaky, hipStream_t st);
+                   float slope, int do_leaky, hipStream_t st, float *ws, int64_t ws_bytes);
 int stream3x3_head_upfeat(const float *x, int B, int Cin, int H, int W, int64_t bsx,
                           const float *hw, const float *hbias, float *hy, int64_t bshy,
                           const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st);
@@ -100,8 +104,11 @@ int splitk_reduce(const float *partial, const float *bias, const float *residual
 extern "C" int64_t pwc_conv2d_workspace_bytes(int B, int Cin, int H, int W, int Cout, int stride, int dilation) {
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return -1;
     const pwc_conv::SplitPlan sp = split_for(B, Cin, H, W, Cout, stride, dilation);
-    return sp.ksplit > 1 ? (int64_t)sp.ksplit * B * Cout * H * W * (int64_t)sizeof(float) : 0;
+    int64_t need = sp.ksplit > 1 ? (int64_t)sp.ksplit * B * Cout * H * W * (int64_t)sizeof(float) : 0;
+    if (Cout == 2 && stride == 1 && dilation == 1) need = std::max(need, pwc_conv::stream3x3_head_workspace_bytes(B, Cin, H, W));   // Cin slices of the streaming head
+    return need;
 }
+
 
 extern "C" int64_t pwc_conv3x3_packed_bytes(int Cin, int Cout, int dtype) {
     if (Cin <= 0 || Cout <= 0 || dtype != PWC_F32) return -1;
@@ -160,14 +167,16 @@ extern "C" int pwc_conv2d_fwd(const void *x, const void *wp, const void *bias, c
     const bool split = sp.ksplit > 1 && workspace &&
                        workspace_bytes >= (int64_t)sp.ksplit * B * Cout * plane * (int64_t)sizeof(float) &&
                        !(reinterpret_cast<uintptr_t>(workspace) & 3u);
-    if (Cout == 2 && stride == 1 && dilation == 1 && !(split && !pwc_conv::stream3x3_ok(B, Cin, H, W, a.x, a.bsx))) {
+    float *ws = (workspace && !(reinterpret_cast<uintptr_t>(workspace) & 15u)) ? static_cast<float *>(workspace) : nullptr;
+    const bool head_sliced = Cout == 2 && stride == 1 && dilation == 1 && pwc_conv::stream3x3_head_sliced_ok(B, Cin, H, W, a.x, a.bsx, ws, workspace_bytes);
+    if (Cout == 2 && stride == 1 && dilation == 1 && !(split && !head_sliced && !pwc_conv::stream3x3_ok(B, Cin, H, W, a.x, a.bsx))) {
         // 2-channel heads: stream the arena through the LDS ring when the image is wide enough, split Cin over
         // waves when the level is tiny; in between the MFMA kernel (MT=1) is still the fastest
         const float *w_raw = a.wp + mfma_image_floats(Cin, Cout);
         int rc = PWC_EUNSUPPORTED;
-        if (pwc_conv::stream3x3_ok(B, Cin, H, W, a.x, a.bsx))
+        if (head_sliced || pwc_conv::stream3x3_ok(B, Cin, H, W, a.x, a.bsx))
             rc = pwc_conv::stream3x3_head(a.x, w_raw, a.bias, a.residual, a.y, B, Cin, H, W, a.bsx, a.bsy, a.bsr,
-                                          a.slope, a.do_leaky, a.stream);
+                                          a.slope, a.do_leaky, a.stream, ws, workspace_bytes);
         else if ((int64_t)B * H * W <= 4096)
             rc = pwc_conv::run_head(a.x, w_raw, a.bias, a.residual, a.y, B, Cin, H, W, Cout, a.bsx, a.bsy, a.bsr,
                                     a.slope, a.do_leaky, a.stream);

@@ -110,7 +110,10 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
                  const float *__restrict__ hw, const float *__restrict__ hbias, const float *__restrict__ residual,
                  float *__restrict__ hy, int64_t bshy, int64_t bsr, float slope, int do_leaky,
                  // UPFEAT: w [Cin][2][16], y [B,2,2H,2W]
-                 const float *__restrict__ uw, const float *__restrict__ ubias, float *__restrict__ uy, int64_t bsuy) {
+                 const float *__restrict__ uw, const float *__restrict__ ubias, float *__restrict__ uy, int64_t bsuy,
+                 // Cin slices (nslice > 1): grid item v = image v / nslice, channels [s * cslice, min(Cin, (s + 1) * cslice)) with
+                 // s = v % nslice; raw partial sums (no bias / activation / residual) go to item v of hy / uy = the caller's workspace
+                 int nslice, int cslice) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using G = Cfg<TH, KS>;
     constexpr int kTH = G::kTH, kRows = G::kRows, kPieces = G::kPieces, kTileInstr = G::kTileInstr, kVmem = G::kVmem;
@@ -128,12 +131,19 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
     const int bx = bid % tiles_x;
     bid /= tiles_x;
     const int by = bid % tiles_y;
-    const int b = bid / tiles_y;
+    const int b = bid / tiles_y;                                    // output item (image, or image x slice)
     const int x0 = bx * kTW;
     const int y0 = by * kTH;
     const int plane = H * W;
 
-    const float *xb = x + (int64_t)b * bsx;
+    const bool sliced = nslice > 1;
+    const int c_lo = sliced ? (b % nslice) * cslice : 0;
+    const float *xb = x + (int64_t)(sliced ? b / nslice : b) * bsx + (int64_t)c_lo * plane;
+    if (sliced) {
+        Cin = min(cslice, Cin - c_lo);
+        if (MODE & MODE_HEAD) hw += (int64_t)c_lo * kHeadWRow;
+        if (MODE & MODE_UPFEAT) uw += (int64_t)c_lo * kUpWRow;
+    }
     const int nchunks = (Cin + kCK - 1) / kCK;
 
     if (wave == G::kLoaderWave) {
@@ -320,7 +330,7 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
 #pragma unroll
         for (int co = 0; co < 2; ++co) {
             const int64_t o = (int64_t)co * plane + (int64_t)oy * W + ox;
-            const float bv = hbias[co];
+            const float bv = sliced ? 0.f : hbias[co];
             float4 v = make_float4(hacc[0][co] + bv, hacc[1][co] + bv, hacc[2][co] + bv, hacc[3][co] + bv);
             if (do_leaky) { v.x = leaky(v.x, slope); v.y = leaky(v.y, slope); v.z = leaky(v.z, slope); v.w = leaky(v.w, slope); }
             if (residual) {
@@ -334,7 +344,7 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
         const int Wo = 2 * W;
 #pragma unroll
         for (int co = 0; co < 2; ++co) {
-            const float bv = ubias[co];
+            const float bv = sliced ? 0.f : ubias[co];
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 float *p = uy + (int64_t)b * bsuy + (int64_t)co * 4 * plane + (int64_t)(2 * oy + py) * Wo + 2 * ox;
@@ -347,15 +357,75 @@ stream3x3_kernel(const float *__restrict__ x, int Cin, int H, int W, int tiles_x
     }
 }
 
+// Sum of the Cin slices' partial sums in fixed slice order + bias (+ LeakyReLU, + residual for the head): thread = four consecutive
+// outputs of one image; the head's 2 x H x W come first, then the deconvolution's 2 x 2H x 2W.
+__global__ void __launch_bounds__(256)
+stream3x3_slice_reduce_kernel(const float *__restrict__ ph, const float *__restrict__ pu, int nslice, int plane, int head_quads, int quads,
+                              const float *__restrict__ hbias, const float *__restrict__ residual, float *__restrict__ hy, int64_t bshy,
+                              int64_t bsr, float slope, int do_leaky, const float *__restrict__ ubias, float *__restrict__ uy, int64_t bsuy) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (q >= quads) return;
+    const bool head = q < head_quads;
+    const int o = 4 * (head ? q : q - head_quads);                   // offset inside the image's [2][H][W] / [2][2H][2W]
+    const int64_t per = head ? 2 * (int64_t)plane : 8 * (int64_t)plane;
+    const float *p = (head ? ph : pu) + (int64_t)b * nslice * per + o;
+    float4 v = *reinterpret_cast<const float4 *>(p);
+    for (int k = 1; k < nslice; ++k) {
+        const float4 t = *reinterpret_cast<const float4 *>(p + k * per);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float bv = head ? hbias[o / plane] : ubias[o / (4 * plane)];
+    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+    if (head) {
+        if (do_leaky) { v.x = leaky(v.x, slope); v.y = leaky(v.y, slope); v.z = leaky(v.z, slope); v.w = leaky(v.w, slope); }
+        if (residual) {
+            const float4 rr = *reinterpret_cast<const float4 *>(residual + (int64_t)b * bsr + o);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        *reinterpret_cast<float4 *>(hy + (int64_t)b * bshy + o) = v;
+    } else {
+        *reinterpret_cast<float4 *>(uy + (int64_t)b * bsuy + o) = v;
+    }
+}
+
+// Cin slices for launches of a few tiles (predict_flow2 of a single pair is 28 8-row tiles, refused by
+// stream3x3_ok, and ran 81 + 5 us on the split-K MFMA kernel with 2 of 16 couts used -- 5 % of that forward): a tile's workgroup walks
+// Cin chunk by chunk behind one barrier per chunk, so few workgroups x 142 chunks are a latency chain.  The launch is cut along Cin
+// into S slices, (image, slice) pairs run as S x as many <TH4,KS4> workgroups, and stream3x3_slice_reduce_kernel adds the partial sums
+// in fixed order.  Option "stream_slice_wgs" = workgroups to reach (0 = off).  Only under stream3x3_ok's 64 tiles: measured on the whole
+// forward (profiles/r04_ab_stream_slices.txt) batch 1 +3.9 %, batch 2 +2.8 %; slicing the launches the one-pass kernel already takes
+// (level 2 at batch 4, the level-3 / level-4 head + upfeat passes at batch 16) changed nothing (+0.3 % / -0.4 %), so they stay one pass.
+struct SlicePlan { int nslice, cslice; };
+inline SlicePlan slice_plan(int B, int Cin, int H, int W) {
+    SlicePlan p{1, Cin};
+    const int target = pwc::option(pwc::OPT_STREAM_SLICE_WGS);
+    const int64_t nblk8 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8);
+    const int64_t tiles4 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 3) / 4);
+    if (target <= 0 || nblk8 >= 64 || tiles4 * 4 > target * 3) return p;           // the one-pass kernel's range / within 3/4 of the target
+    int S = (int)((target + tiles4 - 1) / tiles4);
+    if (S > 16) S = 16;
+    int cs = ((Cin + S - 1) / S + kCK - 1) / kCK * kCK;                           // whole chunks, at least eight of them
+    if (cs < 32) cs = 32;
+    S = (Cin + cs - 1) / cs;
+    if (S > 1) { p.nslice = S; p.cslice = cs; }
+    return p;
+}
+template <int MODE> inline int64_t slice_ws_bytes(const SlicePlan &p, int B, int H, int W) {
+    if (p.nslice <= 1) return 0;
+    return (int64_t)p.nslice * B * (((MODE & MODE_HEAD) ? 2 : 0) + ((MODE & MODE_UPFEAT) ? 8 : 0)) * H * W * (int64_t)sizeof(float);
+}
+
 template <int MODE, int TH, int KS>
 int launch_cfg(const float *x, int B, int Cin, int H, int W, int64_t bsx,
                const float *hw, const float *hbias, const float *residual, float *hy, int64_t bshy, int64_t bsr,
-               float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
+               float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st,
+               int nslice = 1, int cslice = 0) {
     using G = Cfg<TH, KS>;
     if constexpr ((kRing - 2) * G::kVmem > 63) return PWC_EUNSUPPORTED;      // experiment builds with a deeper ring
     const int tiles_x = (W + kTW - 1) / kTW;
     const int tiles_y = (H + TH - 1) / TH;
-    const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
+    const int64_t nblk = (int64_t)B * nslice * tiles_x * tiles_y;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "stream3x3: grid too large");
     constexpr int kAcc = ((MODE & MODE_HEAD) ? 8 : 0) + ((MODE & MODE_UPFEAT) ? 32 : 0);
     constexpr int ring = kRing * G::kBuf * 4, red = (KS - 1) * kAcc * G::kPix * 4;
@@ -365,7 +435,7 @@ int launch_cfg(const float *x, int B, int Cin, int H, int W, int64_t bsx,
     if (const int rc = pwc::ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), smem, "stream3x3")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(G::kBlockThreads), smem, st,
                        x, Cin, H, W, tiles_x, tiles_y, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky,
-                       uw, ubias, uy, bsuy);
+                       uw, ubias, uy, bsuy, nslice, cslice);
     return pwc::check_launch("stream3x3_kernel");
 }
 
@@ -378,8 +448,20 @@ inline int stream_cfg_override() {
 template <int MODE>
 int launch(const float *x, int B, int Cin, int H, int W, int64_t bsx,
            const float *hw, const float *hbias, const float *residual, float *hy, int64_t bshy, int64_t bsr,
-           float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
+           float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st,
+           float *ws = nullptr, int64_t ws_bytes = 0) {
     const int64_t nblk8 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8);
+    const SlicePlan sp = slice_plan(B, Cin, H, W);
+    if (sp.nslice > 1 && ws && pwc::aligned16(ws) && ws_bytes >= slice_ws_bytes<MODE>(sp, B, H, W) && stream_cfg_override() == 0) {
+        const int plane = H * W;
+        float *ph = ws, *pu = ws + ((MODE & MODE_HEAD) ? (int64_t)sp.nslice * B * 2 * plane : 0);
+        if (const int rc = launch_cfg<MODE, 4, 4>(x, B, Cin, H, W, bsx, hw, nullptr, nullptr, ph, 2 * (int64_t)plane, 0, 0.f, 0,
+                                                  uw, nullptr, pu, 8 * (int64_t)plane, st, sp.nslice, sp.cslice)) return rc;
+        const int head_quads = (MODE & MODE_HEAD) ? plane / 2 : 0, quads = head_quads + ((MODE & MODE_UPFEAT) ? 2 * plane : 0);
+        hipLaunchKernelGGL(stream3x3_slice_reduce_kernel, dim3((unsigned)((quads + 255) / 256), (unsigned)B), dim3(256), 0, st,
+                           ph, pu, sp.nslice, plane, head_quads, quads, hbias, residual, hy, bshy, bsr, slope, do_leaky, ubias, uy, bsuy);
+        return pwc::check_launch("stream3x3_slice_reduce_kernel");
+    }
     int cfg = stream_cfg_override();
     if (cfg != 81 && cfg != 42 && cfg != 44 && cfg != 41) cfg = nblk8 < 256 ? 44 : 81;
 #define PWC_STREAM_GO(TH, KS) return launch_cfg<MODE, TH, KS>(x, B, Cin, H, W, bsx, hw, hbias, residual, hy, bshy, bsr, slope, do_leaky, uw, ubias, uy, bsuy, st)
@@ -397,6 +479,17 @@ inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) 
 namespace pwc_conv {
 
 // true when the streaming kernel applies to this geometry (the callers keep their other kernels otherwise)
+int64_t stream3x3_head_workspace_bytes(int B, int Cin, int H, int W) { return slice_ws_bytes<MODE_HEAD>(slice_plan(B, Cin, H, W), B, H, W); }
+
+// the flow head alone with Cin slices: launches under the 64 tiles stream3x3_ok asks for (predict_flow2 of one or two pairs) fill the
+// chip through their slices -- needs the caller's workspace
+bool stream3x3_head_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes) {
+    static const int min_w = [] { const char *e = getenv("PWC_STREAM_MINW"); return (e && *e) ? atoi(e) : 64; }();
+    const SlicePlan sp = slice_plan(B, Cin, H, W);
+    return sp.nslice > 1 && ws && al16(ws) && ws_bytes >= slice_ws_bytes<MODE_HEAD>(sp, B, H, W) && (W % 4 == 0) && (W >= min_w) && al16(x) &&
+           (bsx % 4 == 0) && ((int64_t)H * W * kCK * 4 < 0x7fffffffLL) && (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8) >= 8;
+}
+
 bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx) {
     static const int min_w = [] { const char *e = getenv("PWC_STREAM_MINW"); return (e && *e) ? atoi(e) : 64; }();    // 64-column maps (level 4) run half-filled 128-column tiles: still ahead of split-K MFMA head + deconv (-45 us)
     return (W % 4 == 0) && (W >= min_w) && al16(x) && (bsx % 4 == 0) && ((int64_t)H * W * kCK * 4 < 0x7fffffffLL) &&
@@ -406,10 +499,10 @@ bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx) {
 // w = packed head taps [Cin][20] (tail of pwc_conv3x3_pack's buffer for Cout == 2)
 int stream3x3_head(const float *x, const float *w, const float *bias, const float *residual, float *y,
                    int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, int64_t bsr,
-                   float slope, int do_leaky, hipStream_t st) {
+                   float slope, int do_leaky, hipStream_t st, float *ws, int64_t ws_bytes) {
     if (!al16(y) || (bsy % 4) || !al16(w) || (residual && (!al16(residual) || (bsr % 4)))) return PWC_EUNSUPPORTED;
     return launch<MODE_HEAD>(x, B, Cin, H, W, bsx, w, bias, residual, y, bsy, bsr, slope, do_leaky,
-                             nullptr, nullptr, nullptr, 0, st);
+                             nullptr, nullptr, nullptr, 0, st, ws, ws_bytes);
 }
 
 // w = nn.ConvTranspose2d weight [Cin][2][4][4]

@@ -677,6 +677,62 @@ def test_streaming_head_deconv_and_fused_entry(dev, geom):
     assert not ops.head_upfeat_supported(16, 7, 16)
 
 
+@pytest.mark.parametrize("geom", [(1, 565, 112, 256),    # predict_flow2 of ONE pair: 28 8-row tiles -> 10 slices of 60 channels, the last one 25
+                                  (2, 565, 112, 256),    # two pairs: 56 tiles -> 5 slices of 116 (the last: 101, a ragged chunk)
+                                  (3, 149, 58, 128),     # 24 tiles, ragged rows -> 5 slices of 32 (the last: 21)
+                                  (1, 53, 34, 132)])     # two tile columns, the second 4 px wide: 10 tiles -> 2 slices of 32 / 21
+def test_streaming_head_cin_slices(dev, geom):
+    """The 2-channel flow head on a map of 8..63 tiles (predict_flow2 of one or two pairs, PWCNet.py:263) runs the streaming kernel
+    on Cin slices (option stream_slice_wgs; partial sums in the caller's workspace, fixed-order reduction) instead of the split-K
+    MFMA kernel: against fp64 conv2d, against the MFMA route (option 0), with bias, LeakyReLU and residual, NaN-filled outputs and
+    workspace (an unwritten element must not pass), a batch-strided operand, bit-repeatable; without a workspace the MFMA route."""
+    from opticalflow_amd import ops, _lib
+    B, cin, H, W = geom
+    assert not ops.head_upfeat_supported(B, H, W)                   # under the one-pass kernel's 64 tiles
+    x = seeded_rand((B, cin, H, W), 310, -1, 1)
+    hw = seeded_rand((2, cin, 3, 3), 311, -1, 1) * 0.05
+    hb = seeded_rand((2,), 312, -0.5, 0.5)
+    res = seeded_rand((B, 2, H, W), 315, -1, 1)
+    torch.set_num_threads(8)
+    ref_h = F.conv2d(x.double(), hw.double(), hb.double(), padding=1)
+    arena = torch.zeros((B, cin + 7, H, W), device=dev)
+    arena[:, 7:] = x.to(dev)
+    xin = arena[:, 7:]
+    hp = ops.pack_conv3x3(hw.to(dev))
+    saved = _lib.get_option("stream_slice_wgs")
+    bound = 3e-6 * (9 * cin) ** 0.5
+    try:
+        out = {}
+        for mode in (saved or 512, 0):
+            _lib.set_option("stream_slice_wgs", mode)
+            need = ops.conv3x3_workspace_bytes(B, cin, H, W, 2)
+            if mode:
+                assert need >= 2 * B * 2 * H * W * 4                # at least two slices' partial sums
+            ws = torch.full((max(need, 16) // 4,), float("nan"), device=dev)
+            y = torch.full((B, 2, H, W), float("nan"), device=dev)
+            ops.conv3x3(xin, hp, hb.to(dev), 2, leaky_slope=None, residual=res.to(dev), out=y, workspace=ws)
+            y2 = torch.full((B, 2, H, W), float("nan"), device=dev)
+            ops.conv3x3(xin, hp, hb.to(dev), 2, leaky_slope=None, residual=res.to(dev), out=y2, workspace=ws)
+            assert torch.equal(y, y2)
+            yl = torch.full((B, 2, H, W), float("nan"), device=dev)
+            ops.conv3x3(xin, hp, hb.to(dev), 2, leaky_slope=0.1, out=yl, workspace=ws)
+            e = (y.cpu().double() - (ref_h + res.double())).abs().max().item()
+            el = (yl.cpu().double() - F.leaky_relu(ref_h, 0.1)).abs().max().item()
+            print("stream_slice_wgs=%d %s: head max err %.2e / %.2e (bound %.2e)" % (mode, geom, e, el, bound))
+            assert e < bound and el < bound
+            out[mode] = (y, yl)
+        yn = ops.conv3x3(xin, hp, hb.to(dev), 2, leaky_slope=None, residual=res.to(dev))      # no workspace: not sliced
+        _lib.set_option("stream_slice_wgs", saved or 512)
+        yn2 = ops.conv3x3(xin, hp, hb.to(dev), 2, leaky_slope=None, residual=res.to(dev))
+        assert torch.equal(yn, yn2)
+        a, b = out[saved or 512], out[0]
+        assert not torch.equal(a[0], b[0])                          # the two routes sum in different orders: really two kernels
+        for i in range(2):
+            assert (a[i] - b[i]).abs().max().item() < 2 * bound
+    finally:
+        _lib.set_option("stream_slice_wgs", saved)
+
+
 # ------------------------------------------------------------------ full forward
 def _golden_net(dev, **kw):
     from opticalflow_amd import PWCDCNet
