@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PWC_ABI_VERSION 11
+#define PWC_ABI_VERSION 12
 
 /* element types */
 #define PWC_F32 0
@@ -83,9 +83,9 @@ const char *pwc_last_error(void);
  *   calls it fuses -- same bits, measured slower at batch 16),
  *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off),
  *   "stream_slice_wgs" [PWC_STREAM_SLICE_WGS] 512 (pwc_conv2d_fwd, 2-channel flow head on a map of 8..63 8-row x 128-column tiles --
- *   predict_flow2 of one or two pairs, PWCNet.py:263: the streaming kernel runs on Cin slices, as many as bring the launch to this many
- *   workgroups, partial sums in the caller's workspace (pwc_conv2d_workspace_bytes covers them), fixed-order reduction; 0: the split-K
- *   MFMA kernel as before),
+ *   predict_flow2 of one or two pairs, PWCNet.py:263 -- and pwc_head_upfeat_ws_fwd on fewer than 256 tiles: the streaming kernel runs
+ *   on Cin slices, as many as bring the launch to this many workgroups, partial sums in the caller's workspace
+ *   (pwc_conv2d_workspace_bytes / pwc_head_upfeat_workspace_bytes), fixed-order reduction; 0: one pass / the split-K MFMA kernel),
  *   "c1_in_arena" [PWC_C1_IN_ARENA] 1 (fp32 plans: the level features of both images live at the arena's batch stride, so that the pyramid's
  *   last convolution writes the first image's straight into their arena slot; 0: dense pyramid buffers and one copy per level).
  * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */
@@ -346,6 +346,16 @@ int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const void *head_bia
                         const void *up_w, const void *up_bias, void *up_out,
                         int B, int Cin, int H, int W, int dtype,
                         int64_t x_bstride, int64_t flow_bstride, int64_t up_bstride, void *stream);
+/* The same with a scratch buffer of pwc_head_upfeat_workspace_bytes(B, Cin, H, W) bytes (0: this geometry never uses one; ABI v12):
+ * launches of fewer than 256 8-row x 128-column tiles -- fewer workgroups than the chip has CUs, each VALU-bound on its own CU -- are
+ * cut along Cin into slices (option "stream_slice_wgs") whose partial sums meet in the workspace and are added in fixed slice order:
+ * deterministic; the fp32 summation order differs from the one-pass form.  workspace NULL / too small: the one-pass form. */
+int64_t pwc_head_upfeat_workspace_bytes(int B, int Cin, int H, int W);
+int pwc_head_upfeat_ws_fwd(const void *x, const void *head_wp, const void *head_bias, void *flow,
+                           const void *up_w, const void *up_bias, void *up_out,
+                           int B, int Cin, int H, int W, int dtype,
+                           int64_t x_bstride, int64_t flow_bstride, int64_t up_bstride,
+                           void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Profiling calibration, not on the product path: streams `nbytes` (a multiple of 64*width) of src through LDS with the
  * kernels' own LDS-DMA instruction (width 4: buffer_load_dword ... lds, width 16: buffer_load_dwordx4 ... lds) so that rocprofv3's

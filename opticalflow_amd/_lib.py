@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PWC_HIP_LIB: alternative build of the same C ABI (kernel experiments); default = the in-tree library
 LIB_PATH = os.environ.get("PWC_HIP_LIB") or os.path.join(_HERE, "libpwc_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PWC_F32, PWC_F16 = 0, 1
 FLAG_CORR_NORMALIZE = 1
 FLAG_ACT_LEAKY = 2
@@ -91,6 +91,9 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "pwc_head_upfeat_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p]),
+    "pwc_head_upfeat_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "pwc_head_upfeat_ws_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -23,12 +23,13 @@ int image_conv_s2(const float *x, const float *wp, const float *bias, float *y, 
 bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx);
 bool stream3x3_head_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes);
 int64_t stream3x3_head_workspace_bytes(int B, int Cin, int H, int W);
+int64_t stream3x3_head_upfeat_workspace_bytes(int B, int Cin, int H, int W);
 int stream3x3_head(const float *x, const float *w, const float *bias, const float *residual, float *y,
                    int B, int Cin, int H, int W, int64_t bsx, int64_t bsy, int64_t bsr,
                    float slope, int do_leaky, hipStream_t st, float *ws, int64_t ws_bytes);
 int stream3x3_head_upfeat(const float *x, int B, int Cin, int H, int W, int64_t bsx,
                           const float *hw, const float *hbias, float *hy, int64_t bshy,
-                          const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st);
+                          const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st, float *ws, int64_t ws_bytes);
 }  // namespace pwc_conv
 
 namespace {
@@ -213,6 +214,22 @@ extern "C" int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const voi
                                    const void *up_w, const void *up_bias, void *up_out,
                                    int B, int Cin, int H, int W, int dtype,
                                    int64_t x_bstride, int64_t flow_bstride, int64_t up_bstride, void *stream) {
+    return pwc_head_upfeat_ws_fwd(x, head_wp, head_bias, flow, up_w, up_bias, up_out, B, Cin, H, W, dtype, x_bstride, flow_bstride, up_bstride,
+                                  nullptr, 0, stream);
+}
+
+extern "C" int64_t pwc_head_upfeat_workspace_bytes(int B, int Cin, int H, int W) {
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0) return -1;
+    return pwc_conv::stream3x3_head_upfeat_workspace_bytes(B, Cin, H, W);
+}
+
+// The same with a scratch buffer (pwc_head_upfeat_workspace_bytes): launches of fewer tiles than the chip has CUs are cut along Cin into
+// slices (pwc_stream3x3.hip: slice_plan), partial sums in the workspace, fixed-order reduction.  Without one (or too small): one pass.
+extern "C" int pwc_head_upfeat_ws_fwd(const void *x, const void *head_wp, const void *head_bias, void *flow,
+                                      const void *up_w, const void *up_bias, void *up_out,
+                                      int B, int Cin, int H, int W, int dtype,
+                                      int64_t x_bstride, int64_t flow_bstride, int64_t up_bstride,
+                                      void *workspace, int64_t workspace_bytes, void *stream) {
     if (!x || !head_wp || !head_bias || !flow || !up_w || !up_bias || !up_out) PWC_FAIL(PWC_EINVAL, "pwc_head_upfeat_fwd: null pointer");
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0) PWC_FAIL(PWC_EINVAL, "pwc_head_upfeat_fwd: bad shape");
     if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_head_upfeat_fwd: dtype %d", dtype);
@@ -226,7 +243,7 @@ extern "C" int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const voi
     const int rc = pwc_conv::stream3x3_head_upfeat(xf, B, Cin, H, W, x_bstride, w_raw, static_cast<const float *>(head_bias),
                                                    static_cast<float *>(flow), flow_bstride, static_cast<const float *>(up_w),
                                                    static_cast<const float *>(up_bias), static_cast<float *>(up_out), up_bstride,
-                                                   static_cast<hipStream_t>(stream));
+                                                   static_cast<hipStream_t>(stream), static_cast<float *>(workspace), workspace_bytes);
     if (rc == PWC_EUNSUPPORTED) pwc::set_error("pwc_head_upfeat_fwd: outputs must be 16-byte aligned");
     return rc;
 }

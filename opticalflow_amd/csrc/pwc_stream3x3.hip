@@ -393,16 +393,16 @@ stream3x3_slice_reduce_kernel(const float *__restrict__ ph, const float *__restr
 // stream3x3_ok, and ran 81 + 5 us on the split-K MFMA kernel with 2 of 16 couts used -- 5 % of that forward): a tile's workgroup walks
 // Cin chunk by chunk behind one barrier per chunk, so few workgroups x 142 chunks are a latency chain.  The launch is cut along Cin
 // into S slices, (image, slice) pairs run as S x as many <TH4,KS4> workgroups, and stream3x3_slice_reduce_kernel adds the partial sums
-// in fixed order.  Option "stream_slice_wgs" = workgroups to reach (0 = off).  Only under stream3x3_ok's 64 tiles: measured on the whole
-// forward (profiles/r04_ab_stream_slices.txt) batch 1 +3.9 %, batch 2 +2.8 %; slicing the launches the one-pass kernel already takes
-// (level 2 at batch 4, the level-3 / level-4 head + upfeat passes at batch 16) changed nothing (+0.3 % / -0.4 %), so they stay one pass.
+// in fixed order.  Option "stream_slice_wgs" = workgroups to reach (0 = off).  The head alone: only under stream3x3_ok's 64 tiles
+// (profiles/r04_ab_stream_slices.txt: batch 1 +2.3 % in the median, batch 2 +0.7 %; level 2 at batch 4-8, where the one-pass kernel
+// already runs: nothing).  Head + upfeat: up to 256 tiles (profiles/r04_microbench_head_slices.txt: level 4 at batch 16 115 -> 84 us).
 struct SlicePlan { int nslice, cslice; };
-inline SlicePlan slice_plan(int B, int Cin, int H, int W) {
+inline SlicePlan slice_plan(int B, int Cin, int H, int W, int max_tiles8 = 64) {
     SlicePlan p{1, Cin};
     const int target = pwc::option(pwc::OPT_STREAM_SLICE_WGS);
     const int64_t nblk8 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8);
     const int64_t tiles4 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 3) / 4);
-    if (target <= 0 || nblk8 >= 64 || tiles4 * 4 > target * 3) return p;           // the one-pass kernel's range / within 3/4 of the target
+    if (target <= 0 || nblk8 >= max_tiles8 || tiles4 * 4 > target * 3) return p;   // the one-pass kernel's range / within 3/4 of the target
     int S = (int)((target + tiles4 - 1) / tiles4);
     if (S > 16) S = 16;
     int cs = ((Cin + S - 1) / S + kCK - 1) / kCK * kCK;                           // whole chunks, at least eight of them
@@ -451,7 +451,9 @@ int launch(const float *x, int B, int Cin, int H, int W, int64_t bsx,
            float slope, int do_leaky, const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st,
            float *ws = nullptr, int64_t ws_bytes = 0) {
     const int64_t nblk8 = (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8);
-    const SlicePlan sp = slice_plan(B, Cin, H, W);
+    // head + upfeat (100 v_pk_fma_f32 per channel and thread: a workgroup keeps its CU's VALUs busy, so fewer workgroups than CUs leave
+    // the rest of the chip idle) is sliced up to 256 tiles; the head alone only below the one-pass kernel's range
+    const SlicePlan sp = slice_plan(B, Cin, H, W, (MODE & MODE_UPFEAT) ? 256 : 64);
     if (sp.nslice > 1 && ws && pwc::aligned16(ws) && ws_bytes >= slice_ws_bytes<MODE>(sp, B, H, W) && stream_cfg_override() == 0) {
         const int plane = H * W;
         float *ph = ws, *pu = ws + ((MODE & MODE_HEAD) ? (int64_t)sp.nslice * B * 2 * plane : 0);
@@ -483,6 +485,10 @@ int64_t stream3x3_head_workspace_bytes(int B, int Cin, int H, int W) { return sl
 
 // the flow head alone with Cin slices: launches under the 64 tiles stream3x3_ok asks for (predict_flow2 of one or two pairs) fill the
 // chip through their slices -- needs the caller's workspace
+int64_t stream3x3_head_upfeat_workspace_bytes(int B, int Cin, int H, int W) {
+    return slice_ws_bytes<MODE_HEAD | MODE_UPFEAT>(slice_plan(B, Cin, H, W, 256), B, H, W);
+}
+
 bool stream3x3_head_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes) {
     static const int min_w = [] { const char *e = getenv("PWC_STREAM_MINW"); return (e && *e) ? atoi(e) : 64; }();
     const SlicePlan sp = slice_plan(B, Cin, H, W);
@@ -515,10 +521,10 @@ int stream3x3_upfeat(const float *x, const float *w, const float *bias, float *y
 
 int stream3x3_head_upfeat(const float *x, int B, int Cin, int H, int W, int64_t bsx,
                           const float *hw, const float *hbias, float *hy, int64_t bshy,
-                          const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st) {
+                          const float *uw, const float *ubias, float *uy, int64_t bsuy, hipStream_t st, float *ws, int64_t ws_bytes) {
     if (!al16(hy) || (bshy % 4) || !al16(uy) || (bsuy % 4) || !al16(hw) || !al16(uw)) return PWC_EUNSUPPORTED;
     return launch<MODE_HEAD | MODE_UPFEAT>(x, B, Cin, H, W, bsx, hw, hbias, nullptr, hy, bshy, 0, 0.f, 0,
-                                           uw, ubias, uy, bsuy, st);
+                                           uw, ubias, uy, bsuy, st, ws, ws_bytes);
 }
 
 }  // namespace pwc_conv

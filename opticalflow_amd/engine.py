@@ -272,6 +272,8 @@ class PwcPlan:
         need = 0
         for n, cin, h, w, co, dil in self._launch_geometries(B, trunk2):
             need = max(need, ops.conv3x3_workspace_bytes(n, cin, h, w, co, 1, dil))
+            if co == 2 and dil == 1:                            # predict_flowL + upfeatL as one streaming pass, cut along Cin when small
+                need = max(need, ops.head_upfeat_workspace_bytes(n, cin, h, w))
             if self.wino and co >= 32 and dil <= 8:
                 need = max(need, ops.conv3x3_wino_workspace_bytes(n, cin, h, w, co, dil))
             if self.wino and self.wino4 and co >= 32 and dil == 1 and w % 4 == 0:
@@ -453,7 +455,7 @@ class PwcPlan:
             # predict_flowL and upfeatL read the same 3x3 windows of the same arena: one pass
             ops.head_upfeat(ar, self.packed["predict_flow%d" % l], self.p["predict_flow%d.bias" % l],
                             self.p["upfeat%d.weight" % l], self.p["upfeat%d.bias" % l],
-                            self.flow[l], nxt[:, o + 2:o + 4])
+                            self.flow[l], nxt[:, o + 2:o + 4], workspace=self.workspace)
         else:
             self._conv("predict_flow%d" % l, ar, self.flow[l], act=False)
             self._deconv("upfeat%d" % l, ar, nxt[:, o + 2:o + 4])

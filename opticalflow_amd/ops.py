@@ -479,9 +479,18 @@ def head_upfeat_supported(B: int, H: int, W: int) -> bool:
     return W % 4 == 0 and W >= int(os.environ.get("PWC_STREAM_MINW", "64")) and B * ((W + 127) // 128) * ((H + 7) // 8) >= 64
 
 
+def head_upfeat_workspace_bytes(B: int, cin: int, H: int, W: int) -> int:
+    """Scratch bytes pwc_head_upfeat_ws_fwd wants for this geometry (Cin slices of launches smaller than the chip; 0 = never)."""
+    n = _lib.load().pwc_head_upfeat_workspace_bytes(B, cin, H, W)
+    if n < 0:
+        raise ValueError("bad head geometry")
+    return int(n)
+
+
 def head_upfeat(x: torch.Tensor, head_wpacked: torch.Tensor, head_bias: torch.Tensor, up_weight: torch.Tensor,
-                up_bias: torch.Tensor, flow_out: torch.Tensor, up_out: torch.Tensor) -> None:
-    """predict_flowL + upfeatL in one pass over the arena x (fused C-ABI entry pwc_head_upfeat_fwd)."""
+                up_bias: torch.Tensor, flow_out: torch.Tensor, up_out: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> None:
+    """predict_flowL + upfeatL in one pass over the arena x (fused C-ABI entry pwc_head_upfeat_ws_fwd; `workspace`: scratch for the
+    Cin slices of launches smaller than the chip, see head_upfeat_workspace_bytes)."""
     lib = _lib.load()
     bsx = _plane_dense(x, "x")
     B, cin, H, W = x.shape
@@ -495,10 +504,11 @@ def head_upfeat(x: torch.Tensor, head_wpacked: torch.Tensor, head_bias: torch.Te
     bsf = _plane_dense(flow_out, "flow_out")
     bsu = _plane_dense(up_out, "up_out")
     with torch.cuda.device(x.device):
-        rc = lib.pwc_head_upfeat_fwd(x.data_ptr(), head_wpacked.data_ptr(), head_bias.data_ptr(), flow_out.data_ptr(),
-                                     up_weight.data_ptr(), up_bias.data_ptr(), up_out.data_ptr(),
-                                     B, cin, H, W, _dtype_code(x), bsx, bsf, bsu, _stream(x))
-    check(rc, "pwc_head_upfeat_fwd")
+        ws_ptr, ws_bytes = _workspace_args(workspace, x)
+        rc = lib.pwc_head_upfeat_ws_fwd(x.data_ptr(), head_wpacked.data_ptr(), head_bias.data_ptr(), flow_out.data_ptr(),
+                                        up_weight.data_ptr(), up_bias.data_ptr(), up_out.data_ptr(),
+                                        B, cin, H, W, _dtype_code(x), bsx, bsf, bsu, ws_ptr, ws_bytes, _stream(x))
+    check(rc, "pwc_head_upfeat_ws_fwd")
 
 
 def deconv_as_conv3x3(wt: torch.Tensor) -> torch.Tensor:

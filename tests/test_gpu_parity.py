@@ -733,6 +733,55 @@ def test_streaming_head_cin_slices(dev, geom):
         _lib.set_option("stream_slice_wgs", saved)
 
 
+@pytest.mark.parametrize("geom", [(16, 629, 28, 64),     # level 4 at batch 16: 112 half-filled 4-row tiles -> 5 slices of 128 channels (the last: 117)
+                                  (8, 149, 58, 128),     # 120 tiles, ragged rows -> 5 slices of 32 (the last: 21, a ragged chunk)
+                                  (10, 37, 34, 132)])    # two tile columns, the second 4 px wide; 2 slices of 32 / 5
+def test_streaming_head_upfeat_cin_slices(dev, geom):
+    """predict_flowL + upfeatL in one pass (pwc_head_upfeat_ws_fwd) on launches of fewer tiles than the chip has CUs: Cin slices with
+    the caller's workspace against fp64 conv2d / conv_transpose2d (PWCNet.py:32-36, 207-209), against the one-pass form (no
+    workspace), NaN-filled outputs and workspace, batch-strided operand and output, bit-repeatable; option 0 = one pass."""
+    from opticalflow_amd import ops, _lib
+    B, cin, H, W = geom
+    assert ops.head_upfeat_supported(B, H, W)
+    x = seeded_rand((B, cin, H, W), 320, -1, 1)
+    hw = seeded_rand((2, cin, 3, 3), 321, -1, 1) * 0.05
+    hb = seeded_rand((2,), 322, -0.5, 0.5)
+    uw = seeded_rand((cin, 2, 4, 4), 323, -1, 1) * 0.05
+    ub = seeded_rand((2,), 324, -0.5, 0.5)
+    torch.set_num_threads(8)
+    ref_h = F.conv2d(x.double(), hw.double(), hb.double(), padding=1)
+    ref_u = F.conv_transpose2d(x.double(), uw.double(), ub.double(), stride=2, padding=1)
+    arena = torch.zeros((B, cin + 7, H, W), device=dev)
+    arena[:, 7:] = x.to(dev)
+    xin = arena[:, 7:]
+    hp = ops.pack_conv3x3(hw.to(dev))
+    need = ops.head_upfeat_workspace_bytes(B, cin, H, W)
+    assert need >= 2 * B * 10 * H * W * 4                           # at least two slices of the 2 + 8 planes
+    bound = 3e-6 * (9 * cin) ** 0.5
+    got = {}
+    for tag, ws in (("sliced", torch.full((need // 4,), float("nan"), device=dev)), ("one pass", None),
+                    ("short workspace", torch.full((need // 4 - 4,), float("nan"), device=dev))):
+        nxt = torch.full((B, 9, 2 * H, 2 * W), float("nan"), device=dev)
+        flow = torch.full((B, 2, H, W), float("nan"), device=dev)
+        ops.head_upfeat(xin, hp, hb.to(dev), uw.to(dev), ub.to(dev), flow, nxt[:, 3:5], workspace=ws)
+        flow2, nxt2 = torch.empty_like(flow), torch.empty_like(nxt)
+        ops.head_upfeat(xin, hp, hb.to(dev), uw.to(dev), ub.to(dev), flow2, nxt2[:, 3:5], workspace=ws)
+        assert torch.equal(flow, flow2) and torch.equal(nxt[:, 3:5], nxt2[:, 3:5])
+        assert torch.isnan(nxt[:, :3]).all() and torch.isnan(nxt[:, 5:]).all()
+        eh, eu = (flow.cpu().double() - ref_h).abs().max().item(), (nxt[:, 3:5].cpu().double() - ref_u).abs().max().item()
+        print("head + upfeat %s %s: max err %.2e / %.2e (bound %.2e)" % (geom, tag, eh, eu, bound))
+        assert eh < bound and eu < bound
+        got[tag] = (flow, nxt[:, 3:5].clone())
+    assert not torch.equal(got["sliced"][1], got["one pass"][1])    # other summation order: the slices really ran
+    assert torch.equal(got["short workspace"][0], got["one pass"][0]) and torch.equal(got["short workspace"][1], got["one pass"][1])
+    saved = _lib.get_option("stream_slice_wgs")
+    try:
+        _lib.set_option("stream_slice_wgs", 0)
+        assert ops.head_upfeat_workspace_bytes(B, cin, H, W) == 0
+    finally:
+        _lib.set_option("stream_slice_wgs", saved)
+
+
 # ------------------------------------------------------------------ full forward
 def _golden_net(dev, **kw):
     from opticalflow_amd import PWCDCNet
