@@ -32,7 +32,7 @@ void note_kernel(const char *name, int a, int b, int c, int d, int e, int f) {
 // once at first use, so a test could only flip one if it ran before that use).  The environment variable still gives the
 // DEFAULT -- read the first time the option is looked at -- and pwc_set_option() overrides it at any time, for every thread.
 struct OptDesc { const char *name, *env; int dflt; };
-static const OptDesc kOpts[OPT_COUNT] = {
+static constexpr OptDesc kOpts[OPT_COUNT] = {
     {"conv_wino4", "PWC_CONV_WINO4", 1},                  // F(4x4) route allowed (pwc_conv3x3_wino4_preferred)
     {"w4_tailsplit", "PWC_W4_TAILSPLIT", 1},              // partial last round of an F(4x4) launch cut along Cin
     {"w4_smallsplit", "PWC_W4_SMALLSPLIT", 1},            // launches that do not fill the chip cut along Cin (small batches)
@@ -51,6 +51,18 @@ static const OptDesc kOpts[OPT_COUNT] = {
     {"c1_in_arena", "PWC_C1_IN_ARENA", 1},                // fp32 plans: the pyramid's last convolution of levels 2-5 writes the first image's features straight into
                                                           // their slot of the decoder arena (batch-strided output) instead of a copy per level (read by the Python engine)
 };
+// the table is indexed by enum Opt (pwc_common.h): a row out of order would silently give one switch another's value
+constexpr bool opt_is(Opt o, const char *name) {
+    const char *a = kOpts[o].name;
+    while (*a && *a == *name) { ++a; ++name; }
+    return *a == *name;
+}
+static_assert(opt_is(OPT_CONV_WINO4, "conv_wino4") && opt_is(OPT_W4_TAILSPLIT, "w4_tailsplit") && opt_is(OPT_W4_SMALLSPLIT, "w4_smallsplit") &&
+              opt_is(OPT_W4_SMALL_MIN_WGS, "w4_small_min_wgs") && opt_is(OPT_CORR_PIPE, "corr_pipe") &&
+              opt_is(OPT_CORR_PIPE_MIN_TILES, "corr_pipe_min_tiles") && opt_is(OPT_CORR_ROLL, "corr_roll") &&
+              opt_is(OPT_CORR_SMALL_TILES, "corr_small_tiles") && opt_is(OPT_HEAD10, "head10") && opt_is(OPT_F16_LEVEL_CORR, "f16_level_corr") &&
+              opt_is(OPT_WARPCORR_WINDOW, "warpcorr_window") && opt_is(OPT_STREAM_SLICE_WGS, "stream_slice_wgs") &&
+              opt_is(OPT_C1_IN_ARENA, "c1_in_arena"), "kOpts rows follow enum Opt");
 static std::atomic<int> g_opt_val[OPT_COUNT];
 static std::atomic<unsigned char> g_opt_set[OPT_COUNT];
 
