@@ -86,6 +86,9 @@ const char *pwc_last_error(void);
  *   predict_flow2 of one or two pairs, PWCNet.py:263 -- and pwc_head_upfeat_ws_fwd on fewer than 256 tiles: the streaming kernel runs
  *   on Cin slices, as many as bring the launch to this many workgroups, partial sums in the caller's workspace
  *   (pwc_conv2d_workspace_bytes / pwc_head_upfeat_workspace_bytes), fixed-order reduction; 0: one pass / the split-K MFMA kernel),
+ *   "head_sliced_min_tiles" [PWC_HEAD_SLICED_MIN_TILES] 14 (fp32 plans: levels of at least this many 8-row x 128-column tiles run predict_flowL +
+ *   upfeatL through pwc_head_upfeat_ws_fwd -- on Cin slices below the 64 tiles its one-pass form needs -- instead of the 10-channel
+ *   convolution of "head10"; 64: only where the one-pass kernel runs),
  *   "c1_in_arena" [PWC_C1_IN_ARENA] 1 (fp32 plans: the level features of both images live at the arena's batch stride, so that the pyramid's
  *   last convolution writes the first image's straight into their arena slot; 0: dense pyramid buffers and one copy per level).
  * Unknown name: PWC_EINVAL.  A captured HIP graph keeps the kernels chosen at capture time. */
@@ -349,7 +352,8 @@ int pwc_head_upfeat_fwd(const void *x, const void *head_wp, const void *head_bia
 /* The same with a scratch buffer of pwc_head_upfeat_workspace_bytes(B, Cin, H, W) bytes (0: this geometry never uses one; ABI v12):
  * launches of fewer than 256 8-row x 128-column tiles -- fewer workgroups than the chip has CUs, each VALU-bound on its own CU -- are
  * cut along Cin into slices (option "stream_slice_wgs") whose partial sums meet in the workspace and are added in fixed slice order:
- * deterministic; the fp32 summation order differs from the one-pass form.  workspace NULL / too small: the one-pass form. */
+ * deterministic; the fp32 summation order differs from the one-pass form.  workspace NULL / too small: the one-pass form.  With the
+ * workspace the entry also takes launches of 4..63 tiles (PWC_EUNSUPPORTED without it, as pwc_head_upfeat_fwd). */
 int64_t pwc_head_upfeat_workspace_bytes(int B, int Cin, int H, int W);
 int pwc_head_upfeat_ws_fwd(const void *x, const void *head_wp, const void *head_bias, void *flow,
                            const void *up_w, const void *up_bias, void *up_out,

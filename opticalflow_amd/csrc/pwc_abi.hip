@@ -50,6 +50,9 @@ static constexpr OptDesc kOpts[OPT_COUNT] = {
                                                           // into slices (fixed-order reduction, needs the caller's workspace); 0 = off
     {"c1_in_arena", "PWC_C1_IN_ARENA", 1},                // fp32 plans: the pyramid's last convolution of levels 2-5 writes the first image's features straight into
                                                           // their slot of the decoder arena (batch-strided output) instead of a copy per level (read by the Python engine)
+    {"head_sliced_min_tiles", "PWC_HEAD_SLICED_MIN_TILES", 14},   // fp32 plans: levels of at least this many 8-row x 128-column tiles run predict_flowL + upfeatL through
+                                                          // pwc_head_upfeat_ws_fwd (Cin slices below 64 tiles) instead of the 10-channel convolution; 64 = only where the one-pass
+                                                          // kernel runs (read by the Python engine)
 };
 // the table is indexed by enum Opt (pwc_common.h): a row out of order would silently give one switch another's value
 constexpr bool opt_is(Opt o, const char *name) {
@@ -62,7 +65,7 @@ static_assert(opt_is(OPT_CONV_WINO4, "conv_wino4") && opt_is(OPT_W4_TAILSPLIT, "
               opt_is(OPT_CORR_PIPE_MIN_TILES, "corr_pipe_min_tiles") && opt_is(OPT_CORR_ROLL, "corr_roll") &&
               opt_is(OPT_CORR_SMALL_TILES, "corr_small_tiles") && opt_is(OPT_HEAD10, "head10") && opt_is(OPT_F16_LEVEL_CORR, "f16_level_corr") &&
               opt_is(OPT_WARPCORR_WINDOW, "warpcorr_window") && opt_is(OPT_STREAM_SLICE_WGS, "stream_slice_wgs") &&
-              opt_is(OPT_C1_IN_ARENA, "c1_in_arena"), "kOpts rows follow enum Opt");
+              opt_is(OPT_C1_IN_ARENA, "c1_in_arena") && opt_is(OPT_HEAD_SLICED_MIN_TILES, "head_sliced_min_tiles"), "kOpts rows follow enum Opt");
 static std::atomic<int> g_opt_val[OPT_COUNT];
 static std::atomic<unsigned char> g_opt_set[OPT_COUNT];
 

@@ -16,7 +16,7 @@ void set_error(const char *fmt, ...);
 void note_kernel(const char *name, int a, int b, int c, int d, int e, int f);
 
 // run-time options (pwc_abi.hip): default from the environment variable, overridden by the C-ABI pwc_set_option()
-enum Opt { OPT_CONV_WINO4, OPT_W4_TAILSPLIT, OPT_W4_SMALLSPLIT, OPT_W4_SMALL_MIN_WGS, OPT_CORR_PIPE, OPT_CORR_PIPE_MIN_TILES, OPT_CORR_ROLL, OPT_CORR_SMALL_TILES, OPT_HEAD10, OPT_F16_LEVEL_CORR, OPT_WARPCORR_WINDOW, OPT_STREAM_SLICE_WGS, OPT_C1_IN_ARENA, OPT_COUNT };
+enum Opt { OPT_CONV_WINO4, OPT_W4_TAILSPLIT, OPT_W4_SMALLSPLIT, OPT_W4_SMALL_MIN_WGS, OPT_CORR_PIPE, OPT_CORR_PIPE_MIN_TILES, OPT_CORR_ROLL, OPT_CORR_SMALL_TILES, OPT_HEAD10, OPT_F16_LEVEL_CORR, OPT_WARPCORR_WINDOW, OPT_STREAM_SLICE_WGS, OPT_C1_IN_ARENA, OPT_HEAD_SLICED_MIN_TILES, OPT_COUNT };
 int option(Opt o);
 
 inline int check_launch(const char *what) {

@@ -22,6 +22,7 @@ int image_conv_s2(const float *x, const float *wp, const float *bias, float *y, 
                   int64_t bsx, int64_t bsy, float slope, int do_leaky, hipStream_t st);      // pwc_conv_image.hip
 bool stream3x3_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx);
 bool stream3x3_head_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes);
+bool stream3x3_head_upfeat_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes);
 int64_t stream3x3_head_workspace_bytes(int B, int Cin, int H, int W);
 int64_t stream3x3_head_upfeat_workspace_bytes(int B, int Cin, int H, int W);
 int stream3x3_head(const float *x, const float *w, const float *bias, const float *residual, float *y,
@@ -235,7 +236,8 @@ extern "C" int pwc_head_upfeat_ws_fwd(const void *x, const void *head_wp, const 
     if (dtype != PWC_F32) PWC_FAIL(PWC_EUNSUPPORTED, "pwc_head_upfeat_fwd: dtype %d", dtype);
     if (x_bstride < (int64_t)Cin * H * W) PWC_FAIL(PWC_EINVAL, "pwc_head_upfeat_fwd: x batch stride < Cin*H*W");
     const float *xf = static_cast<const float *>(x);
-    if (!pwc_conv::stream3x3_ok(B, Cin, H, W, xf, x_bstride)) {
+    if (!pwc_conv::stream3x3_ok(B, Cin, H, W, xf, x_bstride) &&
+        !pwc_conv::stream3x3_head_upfeat_sliced_ok(B, Cin, H, W, xf, x_bstride, workspace, workspace_bytes)) {
         pwc::set_error("pwc_head_upfeat_fwd: geometry %dx%dx%dx%d outside the streaming kernel (needs W %% 4 == 0, W >= 64)", B, Cin, H, W);
         return PWC_EUNSUPPORTED;
     }

@@ -489,6 +489,15 @@ int64_t stream3x3_head_upfeat_workspace_bytes(int B, int Cin, int H, int W) {
     return slice_ws_bytes<MODE_HEAD | MODE_UPFEAT>(slice_plan(B, Cin, H, W, 256), B, H, W);
 }
 
+// head + upfeat below stream3x3_ok's 64 tiles: possible with Cin slices and the caller's workspace (the plan decides whether it beats
+// the 10-channel convolution there: option "head_sliced_min_tiles", read by the Python engine)
+bool stream3x3_head_upfeat_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes) {
+    static const int min_w = [] { const char *e = getenv("PWC_STREAM_MINW"); return (e && *e) ? atoi(e) : 64; }();
+    const SlicePlan sp = slice_plan(B, Cin, H, W, 256);
+    return sp.nslice > 1 && ws && al16(ws) && ws_bytes >= slice_ws_bytes<MODE_HEAD | MODE_UPFEAT>(sp, B, H, W) && (W % 4 == 0) && (W >= min_w) &&
+           al16(x) && (bsx % 4 == 0) && ((int64_t)H * W * kCK * 4 < 0x7fffffffLL) && (int64_t)B * ((W + kTW - 1) / kTW) * ((H + 7) / 8) >= 4;
+}
+
 bool stream3x3_head_sliced_ok(int B, int Cin, int H, int W, const void *x, int64_t bsx, const void *ws, int64_t ws_bytes) {
     static const int min_w = [] { const char *e = getenv("PWC_STREAM_MINW"); return (e && *e) ? atoi(e) : 64; }();
     const SlicePlan sp = slice_plan(B, Cin, H, W);

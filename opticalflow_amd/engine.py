@@ -145,9 +145,14 @@ class PwcPlan:
         # with four output phases per channel) and ops.upsample_entry finishes the level -- the VALU deconvolution kernel took 21-26 us
         # per launch there.  flow[l] is then channels 0,1 of that convolution's output.
         self.head10: Dict[int, torch.Tensor] = {}
+        # predict_flowL + upfeatL as one streaming pass: where its one-pass kernel runs (64 tiles) and, on Cin slices through the plan's
+        # workspace, down to "head_sliced_min_tiles" tiles (level 3 of 2..8 pairs: 20-36 us ahead of the 10-channel convolution)
+        self.stream_head = {l: conv_backend == "hip" and ops.head_upfeat_supported(
+            B, *self.size[l], min_tiles=_lib.get_option("head_sliced_min_tiles") if _lib.get_option("stream_slice_wgs") > 0 else 64)
+            for l in range(3, 7)}
         if conv_backend == "hip" and _lib.get_option("head10"):
             for l in range(3, 7):
-                if not ops.head_upfeat_supported(B, *self.size[l]):
+                if not self.stream_head[l]:
                     self.head10[l] = torch.empty((B, 10, *self.size[l]), **kw)
                     self.flow[l] = self.head10[l][:, 0:2]
         h2, w2 = self.size[2]
@@ -451,7 +456,7 @@ class PwcPlan:
             self._conv("head10_%d" % l, ar, self.head10[l], act=False)
             ops.upsample_entry(self.head10[l], self.p["deconv%d.weight" % l], self.p["deconv%d.bias" % l], nxt[:, o:o + 4])
             return
-        if self.conv_backend == "hip" and ops.head_upfeat_supported(self.B, h, w):
+        if self.stream_head[l]:
             # predict_flowL and upfeatL read the same 3x3 windows of the same arena: one pass
             ops.head_upfeat(ar, self.packed["predict_flow%d" % l], self.p["predict_flow%d.bias" % l],
                             self.p["upfeat%d.weight" % l], self.p["upfeat%d.bias" % l],

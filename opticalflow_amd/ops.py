@@ -474,9 +474,11 @@ def conv3x3_workspace_bytes(B: int, cin: int, H: int, W: int, cout: int, stride:
     return int(n)
 
 
-def head_upfeat_supported(B: int, H: int, W: int) -> bool:
-    """Geometry gate of pwc_head_upfeat_fwd (mirrors stream3x3_ok in csrc/pwc_stream3x3.hip)."""
-    return W % 4 == 0 and W >= int(os.environ.get("PWC_STREAM_MINW", "64")) and B * ((W + 127) // 128) * ((H + 7) // 8) >= 64
+def head_upfeat_supported(B: int, H: int, W: int, min_tiles: int = 64) -> bool:
+    """Geometry gate of pwc_head_upfeat_fwd (mirrors stream3x3_ok in csrc/pwc_stream3x3.hip).  min_tiles < 64: the gate of
+    pwc_head_upfeat_ws_fwd with a workspace (Cin slices: stream3x3_head_upfeat_sliced_ok, at least 4 tiles)."""
+    return (W % 4 == 0 and W >= int(os.environ.get("PWC_STREAM_MINW", "64"))
+            and B * ((W + 127) // 128) * ((H + 7) // 8) >= max(4, min(64, min_tiles)))
 
 
 def head_upfeat_workspace_bytes(B: int, cin: int, H: int, W: int) -> int:

@@ -735,14 +735,17 @@ def test_streaming_head_cin_slices(dev, geom):
 
 @pytest.mark.parametrize("geom", [(16, 629, 28, 64),     # level 4 at batch 16: 112 half-filled 4-row tiles -> 5 slices of 128 channels (the last: 117)
                                   (8, 149, 58, 128),     # 120 tiles, ragged rows -> 5 slices of 32 (the last: 21, a ragged chunk)
-                                  (10, 37, 34, 132)])    # two tile columns, the second 4 px wide; 2 slices of 32 / 5
+                                  (10, 37, 34, 132),     # two tile columns, the second 4 px wide; 2 slices of 32 / 5
+                                  (2, 597, 56, 128)])    # level 3 of two pairs: 14 tiles, under the one-pass kernel's 64 -> slices only (15 of 40)
 def test_streaming_head_upfeat_cin_slices(dev, geom):
     """predict_flowL + upfeatL in one pass (pwc_head_upfeat_ws_fwd) on launches of fewer tiles than the chip has CUs: Cin slices with
     the caller's workspace against fp64 conv2d / conv_transpose2d (PWCNet.py:32-36, 207-209), against the one-pass form (no
     workspace), NaN-filled outputs and workspace, batch-strided operand and output, bit-repeatable; option 0 = one pass."""
     from opticalflow_amd import ops, _lib
+    from opticalflow_amd._lib import PwcHipError
     B, cin, H, W = geom
-    assert ops.head_upfeat_supported(B, H, W)
+    one_pass = ops.head_upfeat_supported(B, H, W)                   # 64 tiles; below: only with the workspace (at least 4 tiles)
+    assert ops.head_upfeat_supported(B, H, W, min_tiles=4)
     x = seeded_rand((B, cin, H, W), 320, -1, 1)
     hw = seeded_rand((2, cin, 3, 3), 321, -1, 1) * 0.05
     hb = seeded_rand((2,), 322, -0.5, 0.5)
@@ -763,6 +766,11 @@ def test_streaming_head_upfeat_cin_slices(dev, geom):
                     ("short workspace", torch.full((need // 4 - 4,), float("nan"), device=dev))):
         nxt = torch.full((B, 9, 2 * H, 2 * W), float("nan"), device=dev)
         flow = torch.full((B, 2, H, W), float("nan"), device=dev)
+        if tag != "sliced" and not one_pass:
+            with pytest.raises(PwcHipError):                       # nothing launched: the caller takes its other kernels
+                ops.head_upfeat(xin, hp, hb.to(dev), uw.to(dev), ub.to(dev), flow, nxt[:, 3:5], workspace=ws)
+            assert torch.isnan(flow).all() and torch.isnan(nxt).all()
+            continue
         ops.head_upfeat(xin, hp, hb.to(dev), uw.to(dev), ub.to(dev), flow, nxt[:, 3:5], workspace=ws)
         flow2, nxt2 = torch.empty_like(flow), torch.empty_like(nxt)
         ops.head_upfeat(xin, hp, hb.to(dev), uw.to(dev), ub.to(dev), flow2, nxt2[:, 3:5], workspace=ws)
@@ -772,8 +780,9 @@ def test_streaming_head_upfeat_cin_slices(dev, geom):
         print("head + upfeat %s %s: max err %.2e / %.2e (bound %.2e)" % (geom, tag, eh, eu, bound))
         assert eh < bound and eu < bound
         got[tag] = (flow, nxt[:, 3:5].clone())
-    assert not torch.equal(got["sliced"][1], got["one pass"][1])    # other summation order: the slices really ran
-    assert torch.equal(got["short workspace"][0], got["one pass"][0]) and torch.equal(got["short workspace"][1], got["one pass"][1])
+    if one_pass:
+        assert not torch.equal(got["sliced"][1], got["one pass"][1])    # other summation order: the slices really ran
+        assert torch.equal(got["short workspace"][0], got["one pass"][0]) and torch.equal(got["short workspace"][1], got["one pass"][1])
     saved = _lib.get_option("stream_slice_wgs")
     try:
         _lib.set_option("stream_slice_wgs", 0)

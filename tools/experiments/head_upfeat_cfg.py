@@ -5,7 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from opticalflow_amd import ops, _lib
 dev = torch.device("cuda:0")
-for (B, cin, H, W) in [(16, 629, 28, 64), (16, 597, 56, 128), (12, 597, 56, 128)]:
+for (B, cin, H, W) in [(16, 629, 28, 64), (16, 597, 56, 128), (12, 597, 56, 128), (8, 597, 56, 128), (4, 597, 56, 128), (2, 597, 56, 128), (8, 629, 28, 64), (4, 629, 28, 64)]:
     g = torch.Generator().manual_seed(1)
     xs = [torch.rand(B, cin, H, W, generator=g).to(dev) for _ in range(3)]
     hw = (torch.rand(2, cin, 3, 3, generator=g) * 0.05).to(dev); hb = torch.rand(2, generator=g).to(dev)
@@ -15,6 +15,8 @@ for (B, cin, H, W) in [(16, 629, 28, 64), (16, 597, 56, 128), (12, 597, 56, 128)
     need = ops.head_upfeat_workspace_bytes(B, cin, H, W)
     ws = torch.empty(max(need, 16) // 4, device=dev)
     for sliced in (0, 1):
+        if not sliced and not ops.head_upfeat_supported(B, H, W):
+            continue
         def run(i): ops.head_upfeat(xs[i % 3], hp, hb, uw, ub, flow, up, workspace=ws if sliced else None)
         for i in range(6): run(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,7 +29,7 @@ for (B, cin, H, W) in [(16, 629, 28, 64), (16, 597, 56, 128), (12, 597, 56, 128)
             us, B * cin * H * W * 4 / us / 1e6), flush=True)
 
 # the same two layers as ONE 10-channel 3x3 convolution on the matrix cores + pwc_upsample_entry_f32 (the small levels' route, option head10)
-for (B, cin, H, W) in [(16, 629, 28, 64), (16, 597, 56, 128)]:
+for (B, cin, H, W) in [(16, 629, 28, 64), (16, 597, 56, 128), (8, 597, 56, 128), (4, 597, 56, 128), (2, 597, 56, 128), (8, 629, 28, 64), (4, 629, 28, 64)]:
     g = torch.Generator().manual_seed(2)
     xs = [torch.rand(B, cin, H, W, generator=g).to(dev) for _ in range(3)]
     w10 = (torch.rand(10, cin, 3, 3, generator=g) * 0.05).to(dev); b10 = torch.rand(10, generator=g).to(dev)
