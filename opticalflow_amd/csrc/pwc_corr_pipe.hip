@@ -698,12 +698,28 @@ __device__ __forceinline__ float scalar_load(const float *p) {      // wave-unif
     return v;
 }
 
-// window origin of a tile: from the sample position of its centre pixel (halo row 7, halo column 19), the same for every wave
+// two wave-uniform loads in flight at once (u and v of the window origin's flow sample); like scalar_load, outside vmcnt
+__device__ __forceinline__ void scalar_load2(const float *p0, const float *p1, float &v0, float &v1) {
+    asm volatile("s_nop 4\n\ts_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1) : "s"(p0), "s"(p1) : "memory");
+}
+
+// window origin of a tile: from the sample position of its centre pixel (halo row 7, halo column 19), the same for every wave.
+// (The centre pixel's position displaced by the MEAN of the flow at four pixels of the tile leaves 1.1 % instead of 1.8 % of the
+// benchmark's halo pixels outside the window -- tests/flow_window_stats.py "mean4" -- and ran 3.5 us SLOWER: what a tile step can
+// least afford is more work between two tiles, profiles/r04_corr_notes.md section 7.)
 struct WinOrg { int wx0, wy0; };
-__device__ __forceinline__ WinOrg window_origin(const PipeArgs &a, const TileXY &t) {
-    const int gxc = min(t.x0 + 15, a.W - 1), gyc = min(t.y0 + 3, a.H - 1);
-    const float *fu = (const float *)pwc::uniform_ptr(a.flo + (int64_t)t.b * a.bsf + (int64_t)gyc * a.W + gxc);
-    const float u = scalar_load(fu) * a.flow_scale, v = scalar_load(fu + (int64_t)a.H * a.W) * a.flow_scale;
+struct WinCentre { int gxc, gyc; const float *fu; };       // the centre pixel and the address of its u (v one plane behind)
+__device__ __forceinline__ WinCentre window_centre(const PipeArgs &a, const TileXY &t) {
+    WinCentre c;
+    c.gxc = min(t.x0 + 15, a.W - 1); c.gyc = min(t.y0 + 3, a.H - 1);
+    c.fu = a.flo + (int64_t)t.b * a.bsf + (int64_t)c.gyc * a.W + c.gxc;
+    return c;
+}
+// u_raw / v_raw: the flow at the centre pixel as stored (every wave applies the same arithmetic to the same two numbers)
+__device__ __forceinline__ WinOrg window_origin_from(const PipeArgs &a, const TileXY &t, const WinCentre &wc, float u_raw, float v_raw) {
+    const int gxc = wc.gxc, gyc = wc.gyc;
+    const float u = u_raw * a.flow_scale, v = v_raw * a.flow_scale;
     const float px = (float)gxc + u, py = (float)gyc + v;
     const float gx = 2.0f * px / (float)max(a.W - 1, 1) - 1.0f, gy = 2.0f * py / (float)max(a.H - 1, 1) - 1.0f;
     float ix, iy;
@@ -718,6 +734,49 @@ __device__ __forceinline__ WinOrg window_origin(const PipeArgs &a, const TileXY 
     o.wy0 = cy - 7 - kWMy;
     return o;
 }
+// loader waves: scalar loads (their vmcnt is counted by hand), u and v behind ONE wait
+__device__ __forceinline__ WinOrg window_origin(const PipeArgs &a, const TileXY &t) {
+    const WinCentre wc = window_centre(a, t);
+    const float *fu = (const float *)pwc::uniform_ptr(wc.fu);
+    float u, v;
+#ifdef PWC_PIPE_SLOAD1
+    u = scalar_load(fu); v = scalar_load(fu + (int64_t)a.H * a.W);
+#else
+    scalar_load2(fu, fu + (int64_t)a.H * a.W, u, v);
+#endif
+    return window_origin_from(a, t, wc, u, v);
+}
+
+// A workgroup's tiles are known when it starts (blockIdx.x + n gridDim.x), so every wave that needs window origins computes them
+// ALL up front -- lane n: the origin of the workgroup's n-th tile, one round trip of ordinary loads for the whole launch -- and a
+// tile step reads its two integers with v_readlane instead of waiting for two dependent scalar loads between two tiles (the tile
+// step is what the whole workgroup waits for: the two loads behind one wait were worth 2 us of 97, profiles/r04_corr_notes.md
+// section 7).  Tiles past the 64th of a workgroup (batches above ~140 pairs at level 2) take the scalar loads.
+struct OrgTable {
+    int wx, wy;
+    __device__ __forceinline__ void fill(const PipeArgs &a, int lane, int my_tiles) {
+        wx = 0; wy = 0;
+#ifndef PWC_PIPE_NO_ORGTABLE
+        if (lane < my_tiles) {
+            const TileXY t = tile_of((int)blockIdx.x + lane * (int)gridDim.x, a);
+            const WinCentre wc = window_centre(a, t);
+            const WinOrg o = window_origin_from(a, t, wc, wc.fu[0], wc.fu[(int64_t)a.H * a.W]);
+            wx = o.wx0; wy = o.wy0;
+        }
+#endif
+    }
+    __device__ __forceinline__ WinOrg get(const PipeArgs &a, const TileXY &t, int n) const {      // n wave-uniform
+#ifndef PWC_PIPE_NO_ORGTABLE
+        if (n < 64) {
+            WinOrg o;
+            o.wx0 = __builtin_amdgcn_readlane(wx, n);
+            o.wy0 = __builtin_amdgcn_readlane(wy, n);
+            return o;
+        }
+#endif
+        return window_origin(a, t);
+    }
+};
 
 // ---- window loader wave WHICH (0 / 1): instructions WHICH, WHICH + 2, ... of the chunk's 19 --------------------------------
 template <int WHICH>
@@ -725,9 +784,11 @@ struct WinLoader {
     static constexpr int I = (kWinI - WHICH + 1) / 2;       // 10 / 9
     unsigned off[I];
     const float *ip;
-    __device__ __forceinline__ void new_tile(const PipeArgs &a, int tile, int lane, int plane) {
-        const TileXY t = tile_of(tile, a);
-        const WinOrg o = window_origin(a, t);
+    OrgTable tab;
+    // the workgroup's n-th tile
+    __device__ __forceinline__ void new_tile(const PipeArgs &a, int n, int stride, int lane, int plane) {
+        const TileXY t = tile_of((int)blockIdx.x + n * stride, a);
+        const WinOrg o = tab.get(a, t, n);
 #pragma unroll
         for (int j = 0; j < I; ++j) {
             const int p = (WHICH + 2 * j) * 64 + lane;
@@ -757,7 +818,7 @@ __device__ __forceinline__ void win_loader_steps(WinLoader<WHICH> &ld, const Pip
         const int s = t * NCH + K;
         constexpr int kc = (K + kWinSlots) % NCH;
         if (s + kWinSlots < nsteps && !(PWC_PIPE_EXP & 4)) {
-            if constexpr (kc == 0) ld.new_tile(a, (int)blockIdx.x + (t + (K + kWinSlots) / NCH) * stride, lane, plane);
+            if constexpr (kc == 0) ld.new_tile(a, t + (K + kWinSlots) / NCH, stride, lane, plane);
             ld.issue(a, kc, K % kWinSlots, win, plane);
         }
         if (s + kWinSlots < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(I) : "memory");      // chunk s+3 landed, chunk s+4 may fly
@@ -773,7 +834,8 @@ __device__ __forceinline__ void win_loader_wave(const PipeArgs &a, float *win, i
     __builtin_amdgcn_s_setprio(3);
     const int plane = a.H * a.W, stride = gridDim.x, nsteps = my_tiles * NCH;
     WinLoader<WHICH> ld;
-    ld.new_tile(a, blockIdx.x, lane, plane);
+    ld.tab.fill(a, lane, my_tiles);
+    ld.new_tile(a, 0, stride, lane, plane);
 #pragma unroll
     for (int k = 0; k < kWinSlots; ++k) ld.issue(a, k, k, win, plane);      // chunks 0..3 of the first tile (NCH >= 8)
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(I) : "memory");               // chunks 0, 1, 2 have landed
@@ -833,7 +895,7 @@ __device__ __forceinline__ void win_in1_loader_steps(WinLoader<1> &lw, Loader<0,
             l1.issue(a, kc1, (K + kR - 1) % kR, s1ring, nullptr, plane);
         }
         if (gow) {
-            if constexpr (kcw == 0) lw.new_tile(a, (int)blockIdx.x + (t + (K + kWinSlots) / NCH) * stride, lane, plane);
+            if constexpr (kcw == 0) lw.new_tile(a, t + (K + kWinSlots) / NCH, stride, lane, plane);
             lw.issue(a, kcw, K % kWinSlots, win, plane);
         }
         if (go1)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kS1I + I) : "memory");     // (go1 implies gow: kR - 1 > kWinSlots)
@@ -852,7 +914,8 @@ __device__ __forceinline__ void win_in1_loader_wave(const PipeArgs &a, float *s1
     const int plane = a.H * a.W, stride = gridDim.x, nsteps = my_tiles * NCH;
     WinLoader<1> lw;
     Loader<0, kS1I> l1;
-    lw.new_tile(a, blockIdx.x, lane, plane);
+    lw.tab.fill(a, lane, my_tiles);
+    lw.new_tile(a, 0, stride, lane, plane);
     l1.new_tile(a, blockIdx.x, lane, plane);
 #pragma unroll
     for (int k = 0; k < kR - 1; ++k)
@@ -876,12 +939,13 @@ struct ProdPx {                  // one halo pixel of this lane
     float wa, wb_, wc, wd;
 };
 
-struct ProdFlow { float u[kProdPx], v[kProdPx]; WinOrg org; TileXY t; };      // what prod_setup needs from global memory, requested early
+struct ProdFlow { float u[kProdPx], v[kProdPx], cu, cv; WinCentre wc; WinOrg org; TileXY t; int n; };      // what prod_setup needs from global memory, requested early
 
 // the flow at this lane's halo pixels and the window origin of `tile`: issued at the START of the last step of the tile before,
 // used at its end (a dependent global load behind a barrier would cost the producers ~1 us per tile)
-__device__ __forceinline__ void prod_fetch_flow(ProdFlow &pf, const PipeArgs &a, int tile, int pw, int lane) {
-    pf.t = tile_of(tile, a);
+__device__ __forceinline__ void prod_fetch_flow(ProdFlow &pf, const PipeArgs &a, int n, int stride, int pw, int lane) {
+    pf.n = n;
+    pf.t = tile_of((int)blockIdx.x + n * stride, a);
     const int plane = a.H * a.W;
     const float *fu = a.flo + (int64_t)pf.t.b * a.bsf;
 #pragma unroll
@@ -892,10 +956,23 @@ __device__ __forceinline__ void prod_fetch_flow(ProdFlow &pf, const PipeArgs &a,
         pf.u[k] = fu[(int64_t)gyc * a.W + gxc];
         pf.v[k] = fu[(int64_t)plane + (int64_t)gyc * a.W + gxc];
     }
+#if defined(PWC_PIPE_PROD_SLOAD)
     pf.org = window_origin(a, pf.t);
+#elif defined(PWC_PIPE_PROD_VLOAD)
+    // the centre pixel's flow like the pixels' own: ordinary loads of a wave-uniform address, waited for where prod_setup uses them
+    // (the scalar loads of window_origin() block the wave twice per tile, inside the step the whole workgroup waits for)
+    pf.wc = window_centre(a, pf.t);
+    pf.cu = pf.wc.fu[0];
+    pf.cv = pf.wc.fu[plane];
+#endif
 }
 
-__device__ __forceinline__ void prod_setup(ProdPx (&px)[kProdPx], const PipeArgs &a, const ProdFlow &pf, int pw, int lane) {
+__device__ __forceinline__ void prod_setup(ProdPx (&px)[kProdPx], const PipeArgs &a, ProdFlow &pf, const OrgTable &tab, int pw, int lane) {
+#if defined(PWC_PIPE_PROD_VLOAD)
+    pf.org = window_origin_from(a, pf.t, pf.wc, pf.cu, pf.cv);
+#elif !defined(PWC_PIPE_PROD_SLOAD)
+    pf.org = tab.get(a, pf.t, pf.n);          // (the origin's arithmetic is out of the step the whole workgroup waits for)
+#endif
 #pragma unroll
     for (int k = 0; k < kProdPx; ++k) {
         const int hp = (pw * kProdPx + k) * 64 + lane;
@@ -921,6 +998,7 @@ __device__ __forceinline__ void prod_setup(ProdPx (&px)[kProdPx], const PipeArgs
 
 struct ProdState {
     ProdPx px[kProdPx];
+    OrgTable tab;                // window origins of the workgroup's tiles
     const float *src;            // c2 of the tile's batch item
     f32x2 gt[kProdPx][kCK], gb[kProdPx][kCK];     // taps of the pixels outside the window, gathered one step ahead
 };
@@ -995,14 +1073,14 @@ __device__ __forceinline__ void prod_steps(ProdState &ps, const PipeArgs &a, flo
             ProdFlow pf;
             const bool next_tile = (kc == NCH - 1) && (s + 3 < nsteps);
             if constexpr (kc == NCH - 1)
-                if (next_tile) prod_fetch_flow(pf, a, (int)blockIdx.x + (t + (K + 3) / NCH) * stride, pw, lane);
+                if (next_tile) prod_fetch_flow(pf, a, t + (K + 3) / NCH, stride, pw, lane);
             float *dst = s2ring + ((K + 2) % kS2Slots) * kS2F;
             prod_sample(ps, dst, win + ((K + 2) % kWinSlots) * kWinF);
             prod_gather_finish(ps, dst);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is in LDS before this wave reaches the barrier
             if (s + 3 < nsteps) {
                 if constexpr (kc == NCH - 1) {
-                    prod_setup(ps.px, a, pf, pw, lane);
+                    prod_setup(ps.px, a, pf, ps.tab, pw, lane);
                     ps.src = a.in2 + (int64_t)((PWC_PIPE_EXP & 32) ? 0 : pf.t.b) * a.bs2;
                 }
                 prod_gather_issue(ps, a, (kc + 1) % NCH);
@@ -1023,8 +1101,9 @@ __device__ __forceinline__ void producer_wave(const PipeArgs &a, float *s2ring, 
     ProdState ps;
     {
         ProdFlow pf;
-        prod_fetch_flow(pf, a, blockIdx.x, pw, lane);
-        prod_setup(ps.px, a, pf, pw, lane);
+        ps.tab.fill(a, lane, my_tiles);
+        prod_fetch_flow(pf, a, 0, stride, pw, lane);
+        prod_setup(ps.px, a, pf, ps.tab, pw, lane);
         ps.src = a.in2 + (int64_t)((PWC_PIPE_EXP & 32) ? 0 : pf.t.b) * a.bs2;
     }
     prod_gather_issue(ps, a, 0);
