@@ -77,6 +77,31 @@ def test_corr_round4_kernels_bit_equal_round2_kernels(dev, corr_options, shape):
     assert (arena[:, 81:81 + C] == c1).all()
 
 
+def test_corr_window_kernel_more_than_64_tiles_per_workgroup(dev, corr_options):
+    """The fused window kernel keeps the window origins of a workgroup's first 64 tiles in a per-wave table (OrgTable, lane n =
+    tile n) and takes scalar loads for the tiles behind them: 16 640 one-tile images = 65 tiles for each of the 256 workgroups, a
+    ragged channel chunk, flows that leave the window and the image -- bit-identical to the round-2 kernel."""
+    from opticalflow_amd import ops
+    B, C, H, W = 16640, 29, 8, 32
+    g = torch.Generator(device=dev).manual_seed(173)
+    c1 = torch.rand((B, C, H, W), device=dev, generator=g) * 2 - 1
+    c2 = torch.rand((B, C, H, W), device=dev, generator=g) * 2 - 1
+    flo = torch.rand((B, 2, H, W), device=dev, generator=g) * 4 - 2
+    flo[::7] *= 6.0
+    flo[16384:] += 1.5                                                 # the tiles past the table have a flow of their own
+    corr_options("corr_pipe_min_tiles", 1)
+    outs = []
+    for new in (0, 1):
+        corr_options("warpcorr_window", 2 * new)
+        out = torch.full((B, 81, H, W), float("nan"), device=dev)
+        assert ops.warp_correlation(c1, c2, flo, flow_scale=1.25, leaky_slope=0.1, out=out) is not None
+        outs.append(out)
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1])
+    bad = ~(outs[0][16384:] == outs[1][16384:])
+    assert not bad.any()
+
+
 def test_set_option_rejects_unknown_names(dev):
     from opticalflow_amd import _lib
     with pytest.raises(_lib.PwcHipError):
