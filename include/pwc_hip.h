@@ -81,7 +81,7 @@ const char *pwc_last_error(void);
  *   convolution followed by pwc_upsample_entry_f32; 0: pwc_conv2d_fwd + two pwc_deconv4x4s2_fwd),
  *   "f16_level_corr" [PWC_F16_LEVEL_CORR] 0 (1: the half-precision plans enter a level through pwc_level_corr81_c8_f16 instead of the two
  *   calls it fuses -- same bits, measured slower at batch 16),
- *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 1 (fused warp+correlation on the LDS-window kernel: 1 = C <= 32, 2 = also C <= 64, 0 = off),
+ *   "warpcorr_window" [PWC_WARPCORR_WINDOW] 2 (fused warp+correlation on the LDS-window kernel: 2 = C in (28,32] and (60,64], 1 = C <= 32 only, 0 = off),
  *   "stream_slice_wgs" [PWC_STREAM_SLICE_WGS] 512 (pwc_conv2d_fwd, 2-channel flow head on a map of 8..63 8-row x 128-column tiles --
  *   predict_flow2 of one or two pairs, PWCNet.py:263 -- and pwc_head_upfeat_ws_fwd on fewer than 256 tiles: the streaming kernel runs
  *   on Cin slices, as many as bring the launch to this many workgroups, partial sums in the caller's workspace

@@ -45,7 +45,7 @@ static constexpr OptDesc kOpts[OPT_COUNT] = {
     {"head10", "PWC_HEAD10", 1},                          // small levels: flow head + upfeat as one 10-channel convolution + pwc_upsample_entry_f32 (read by the Python engine)
     {"f16_level_corr", "PWC_F16_LEVEL_CORR", 0},          // half-precision plans: level entry + warp + correlation as one kernel (read by the Python engine);
                                                           // bit-identical, but 97 vs 81 us at level 2 (2.5x halo gathers): opt-in
-    {"warpcorr_window", "PWC_WARPCORR_WINDOW", 1},        // fused warp+correlation on the LDS-window kernel: 1 = C <= 32 (level 2), 2 = also C <= 64, 0 = round-2 kernel
+    {"warpcorr_window", "PWC_WARPCORR_WINDOW", 2},        // fused warp+correlation on the LDS-window kernel: 2 = C <= 32 and C <= 64 (levels 2, 3), 1 = C <= 32 only, 0 = round-2 kernel
     {"stream_slice_wgs", "PWC_STREAM_SLICE_WGS", 512},    // streaming flow head (+ upfeat): launches whose 4-row tiles are under 3/4 of this many workgroups are cut along Cin
                                                           // into slices (fixed-order reduction, needs the caller's workspace); 0 = off
     {"c1_in_arena", "PWC_C1_IN_ARENA", 1},                // fp32 plans: the pyramid's last convolution of levels 2-5 writes the first image's features straight into

@@ -883,7 +883,7 @@ extern "C" int pwc_warp_corr81_fwd(const void *in1, const void *x2, const void *
     const int64_t nblk = (int64_t)B * tiles_x * tiles_y;
     if (nblk > 0x7fffffffLL) PWC_FAIL(PWC_EINVAL, "pwc_warp_corr81_fwd: grid too large");
     const float scale = (flags & PWC_CORR_NORMALIZE) ? 1.0f / (float)C : corr_multiply;
-    if (pwc::warp_corr81_pipe_fits(B, C, H, W))       // level 2 of large batches: the LDS-window kernel of pwc_corr_pipe.hip
+    if (pwc::warp_corr81_pipe_fits(B, C, H, W))       // levels 2 and 3: the LDS-window kernel of pwc_corr_pipe.hip
         return pwc::launch_warp_corr81_pipe(static_cast<const float *>(in1), static_cast<const float *>(x2), static_cast<const float *>(flo),
                                             static_cast<float *>(out), B, C, H, W, in1_bstride, x2_bstride, flo_bstride, out_bstride,
                                             flow_scale, align_corners, mask_threshold, scale, leaky_slope, (flags & PWC_ACT_LEAKY) ? 1 : 0,

@@ -1231,14 +1231,19 @@ bool corr81_pipe_fits(int B, int C, int H, int W) {
            (int64_t)H * W * 81 * 4 < 0x7fffffffLL;
 }
 
-// the fused window kernel: level 2 (C <= 32) by default -- at level 3 (448 tiles at batch 16: under two per workgroup) it only ties the
-// round-2 kernel, 49.6 vs 48.9 us; option "warpcorr_window" = 2 takes it there too
+// the fused window kernel: every launch the fused entry gets with C in (28, 32] or (60, 64] -- levels 2 and 3 (option
+// "warpcorr_window": 2 = both, 1 = C <= 32 only, 0 = the round-2 kernel).  It wins at every tile count the engine sends there
+// (pwc_warp_corr81_preferred keeps launches of <= 48 tiles on warp + small-map correlation): level 2 / level 3 of 2, 4, 8, 12, 16, 32
+// pairs 18.0 / 22.6, 29.2 / 23.0, 51.0 / 24.6, 73.8 / 40.4, 93 / 43, 180 / 83.5 us against 20.0 / 29.5, 31.6 / 29.6, 57.0 / 29.8,
+// 96.9 / 44.4, 128 / 47, 246 / 104 for the round-2 kernel (profiles/r04_corr_notes.md, section 8), so "corr_pipe_min_tiles" -- the
+// threshold of the plain ring / rolling kernels -- does not apply to it.  The tile_of() reciprocals need nblk * tiles < 2^32.
 bool warp_corr81_pipe_fits(int B, int C, int H, int W) {
     const int nch = (C + kCK - 1) / kCK, mode = option(OPT_WARPCORR_WINDOW);
-    return mode > 0 && (nch == 8 || (nch == 16 && mode >= 2)) && W >= 2 && corr81_pipe_fits(B, C, H, W);
+    const int64_t tiles_x = (W + kTW - 1) / kTW, tiles_y = (H + kTH - 1) / kTH, nblk = (int64_t)B * tiles_x * tiles_y;
+    return mode > 0 && (nch == 8 || (nch == 16 && mode >= 2)) && W >= 2 && nblk >= 1 && nblk <= 0x7fffffffLL &&
+           nblk * tiles_x < (1ll << 32) && nblk * tiles_y < (1ll << 32) && (int64_t)H * W * 81 * 4 < 0x7fffffffLL;
 }
 
-// reciprocals for tile_of(); false when the exactness bound does not hold (then the caller's other kernels run)
 static bool fill_magic(PipeArgs &a) {
     if (a.tiles_x < 1 || a.tiles_y < 1 || (int64_t)a.nblk * a.tiles_x >= (1ll << 32) || (int64_t)a.nblk * a.tiles_y >= (1ll << 32)) return false;
     a.magic_tx = a.tiles_x == 1 ? 0u : (unsigned)(((1ull << 32) + a.tiles_x - 1) / a.tiles_x);       // (1: not used)
